@@ -1,0 +1,147 @@
+/*
+ * toyfhe_hip.h -- C ABI of libtoyfhe_hip.so, the MI355X (gfx950) engine for the power-of-two
+ * cyclotomic RNS polynomial path of JuliaCrypto/ToyFHE.jl.
+ *
+ * The reference has no FFI: its extension seam is Julia dispatch on the storage type of
+ * RingElement{ℛ,Field,Storage} (src/pow2_cyc_rings.jl:93-96), exactly how src/crt.jl:247-275 plugs
+ * the RNS NTT in.  Each entry point below names the reference method(s) a Julia shim binds it to
+ * (see INTEGRATION.md for the ccall side).  All citations are relative to /root/reference/src/.
+ *
+ * Conventions
+ *   - every function returns 0 (TFHE_OK) or a negative tfhe_status; tfhe_last_error() gives text.
+ *     Nothing aborts or throws across the ABI.
+ *   - residues are uint64_t in [0, q_l); q_l < 2^62, odd primes with 2N | q_l - 1.
+ *   - polynomial data is device memory, layout [count][limbs][N] (limb-major SoA = the StructArray
+ *     field arrays of src/crt.jl:150-156); a ciphertext batch is [batch][polys][limbs][N].
+ *   - limb j of a buffer uses context modulus limb_idx[j] (crtselect, src/crt.jl:185-211);
+ *     limb_idx == NULL means 0..limbs-1.  limb_idx is a HOST array.
+ *   - domain (coefficient "primal" / NTT "dual", src/pow2_cyc_rings.jl:93-145) is tracked by the
+ *     caller; NTT-domain data is in natural order: â[k] = a(ψ^(2k+1)) (src/pow2_cyc_rings.jl:278-294).
+ *   - all work is enqueued on the context's stream (tfhe_ctx_set_stream); calls are asynchronous
+ *     unless stated.  No host pointer is retained after a call returns.
+ */
+#ifndef TOYFHE_HIP_H
+#define TOYFHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    TFHE_OK = 0,
+    TFHE_E_BADARG = -1,          /* @assert-class failures (pow2_cyc_rings.jl:31,61,116; rlwe_she.jl:318) */
+    TFHE_E_DOMAIN = -2,
+    TFHE_E_LEVEL_MISMATCH = -3,
+    TFHE_E_PARAMS_MISMATCH = -4, /* UsageError (rlwe_she.jl:223-225,233-235,248-250) */
+    TFHE_E_NOMEM = -5,
+    TFHE_E_HIP = -6,
+    TFHE_E_UNSUPPORTED = -7      /* error("... only implemented for ...") (crt.jl:270,274) */
+} tfhe_status;
+
+typedef struct tfhe_ctx tfhe_ctx;       /* a ring: NegacyclicRing{CRTEncoded{L,...},N} */
+typedef struct tfhe_bfv_plan tfhe_bfv_plan; /* (ℛ, ℛbig, t) of a BFVParams */
+
+const char *tfhe_last_error(void);      /* thread-local text of the last failure */
+int tfhe_device_count(int *n);
+int tfhe_set_device(int dev);
+
+/* ---- ring context ---------------------------------------------------------------------------
+ * NegacyclicRing{BaseRing,N}(ψ) (pow2_cyc_rings.jl:27-65) / NegacyclicRing(N, logqs) (crt.jl:282-295).
+ * psi[l] == 0 (or psi == NULL) derives GaloisFields.minimal_primitive_root(𝔽q, 2N) (pow2_cyc_rings.jl:40,
+ * crt.jl:142-144); a non-zero psi[l] must satisfy psi^(2N) == 1 (pow2_cyc_rings.jl:31) else TFHE_E_BADARG. */
+int tfhe_ctx_create(int64_t N, int L, const uint64_t *q, const uint64_t *psi, tfhe_ctx **out);
+int tfhe_ctx_destroy(tfhe_ctx *ctx);
+int tfhe_ctx_psi(const tfhe_ctx *ctx, uint64_t *psi_out /* [L] */);
+int tfhe_ctx_set_stream(tfhe_ctx *ctx, void *hip_stream /* hipStream_t, NULL = library-owned */);
+int tfhe_ctx_sync(tfhe_ctx *ctx);
+/* choose the NTT kernel family: 0 = auto (register-blocked LDS kernel when available),
+ * 1 = force the generic radix-2 kernel (cross-check path used by the tests) */
+int tfhe_ctx_set_ntt_variant(tfhe_ctx *ctx, int variant);
+
+/* ---- device memory helpers (for callers without a GPU array package) ------------------------- */
+int tfhe_malloc(size_t bytes, void **dptr);
+int tfhe_free(void *dptr);
+int tfhe_memcpy_h2d(void *dst, const void *src, size_t bytes);  /* synchronous */
+int tfhe_memcpy_d2h(void *dst, const void *src, size_t bytes);  /* synchronous */
+int tfhe_memcpy_d2d(tfhe_ctx *ctx, void *dst, const void *src, size_t bytes); /* on the ctx stream */
+int tfhe_memset(tfhe_ctx *ctx, void *dst, int byte, size_t bytes);
+
+/* ---- K1/K2: nntt / inntt --------------------------------------------------------------------
+ * NTT.nntt / NTT.inntt on RingCoeffs (pow2_cyc_rings.jl:295-318), per limb as crt.jl:247-267.
+ * count = number of polynomials ([count][limbs][N]); src == dst allowed. */
+int tfhe_nntt(tfhe_ctx *ctx, const uint64_t *src, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
+int tfhe_inntt(tfhe_ctx *ctx, const uint64_t *src, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
+
+/* ---- K3/K4: limb-wise arithmetic (crt.jl:120-134; pow2_cyc_rings.jl:167,177-219) -------------- */
+int tfhe_add(tfhe_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
+int tfhe_sub(tfhe_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
+int tfhe_neg(tfhe_ctx *ctx, const uint64_t *a, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
+int tfhe_mul(tfhe_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
+/* dst = acc + a*b (the `c += x*y` pattern of rlwe_she.jl:257,342-343) */
+int tfhe_mad(tfhe_ctx *ctx, const uint64_t *acc, const uint64_t *a, const uint64_t *b, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
+/* scalar_mul (pow2_cyc_rings.jl:177-185): scalar given as residues scal[j] mod q_{limb_idx[j]} (host array) */
+int tfhe_scalar_mul(tfhe_ctx *ctx, const uint64_t *scal, const uint64_t *a, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
+
+/* ---- K5: tensor of two 2-element ciphertexts in the NTT domain (rlwe_she.jl:255-258) ----------
+ * a, b: [batch][2][limbs][N]; out: [batch][3][limbs][N] = (a0 b0, a0 b1 + a1 b0, a1 b1). */
+int tfhe_tensor(tfhe_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t batch, int limbs, const int32_t *limb_idx);
+
+/* ---- K6/K7: level operations ------------------------------------------------------------------
+ * modswitch(::RingElement) (crt.jl:226-228 with :215-220): coefficient domain,
+ * src [count][limbs][N] -> dst [count][limbs-1][N]; c_last taken as its unsigned representative. */
+int tfhe_rescale(tfhe_ctx *ctx, const uint64_t *src, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
+/* crtselect / drop_last / modswitch_drop (crt.jl:185-213,222-236): gather limbs `which` (positions in
+ * the source buffer) of each polynomial: src [count][src_limbs][N] -> dst [count][n_which][N]. */
+int tfhe_select_limbs(tfhe_ctx *ctx, const uint64_t *src, uint64_t *dst, int64_t count, int src_limbs, const int32_t *which, int n_which);
+
+/* ---- K8: apply_galois_element (pow2_cyc_rings.jl:321-329), coefficient domain; src != dst. */
+int tfhe_galois(tfhe_ctx *ctx, const uint64_t *src, uint64_t *dst, uint64_t galois_element, int64_t count, int limbs, const int32_t *limb_idx);
+
+/* ---- K9-K11 (+K6): keyswitch (rlwe_she.jl:315-347) with RNS digits (relin_window == 0, :326-329) --
+ * The KEY ring is the first key_limbs (= Lk) moduli of ctx (ctx may hold further moduli, e.g. a BFV
+ * extension basis).  The ciphertext lives on key limbs 0..level-1.
+ *   special != 0: ModulusRaised (modulusraising.jl:35-49): key modulus Lk-1 is the special prime;
+ *                 expand = *P and append a zero limb, contract = modswitch by P; level <= Lk-1.
+ *   evk: [n_digits][2][Lk][N], component 0 = mask, 1 = masked (rlwe_she.jl:297), NTT domain, full key
+ *        basis; digits 0..level-1 are consumed (rlwe_she.jl:340), n_digits >= level.
+ *   ct:  [batch][polys][level][N], polys in {2,3} (rlwe_she.jl:318), coefficient domain.
+ *   out: [batch][2][level][N], coefficient domain. */
+int tfhe_keyswitch(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint64_t *evk, int n_digits, const uint64_t *ct, int polys, uint64_t *out, int64_t batch);
+/* rotate(gk, c) = keyswitch(gk, apply_galois_element(c, g)) (rlwe_she.jl:355-359) */
+int tfhe_rotate(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint64_t *evk, int n_digits, uint64_t galois_element, const uint64_t *ct, uint64_t *out, int64_t batch);
+
+/* ---- K12/K13: BFV multiplication (rlwe_she.jl:247-262 with bfv.jl:34-40,172-226) ---------------
+ * plan = (ℛ = small ctx limbs idx_s, ℛbig = big ctx limbs idx_b, t).  Supported basis relations:
+ * ℛbig ⊇ ℛ as sets of primes, or disjoint (test/bfv_crt.jl); anything else TFHE_E_UNSUPPORTED.
+ * c1, c2: [batch][2][ns][N]; out: [batch][3][ns][N]; coefficient domain. Exact (bit-identical to
+ * the BigInt path). */
+int tfhe_bfv_plan_create(tfhe_ctx *small, const int32_t *idx_s, int ns, tfhe_ctx *big, const int32_t *idx_b, int nb, uint64_t t, tfhe_bfv_plan **out);
+int tfhe_bfv_plan_destroy(tfhe_bfv_plan *plan);
+int tfhe_bfv_mul(tfhe_bfv_plan *plan, const uint64_t *c1, const uint64_t *c2, uint64_t *out, int64_t batch);
+/* mul_expand (bfv.jl:34, switch :222-226) and mul_contract (bfv.jl:35-40) exposed on their own */
+int tfhe_bfv_expand(tfhe_bfv_plan *plan, const uint64_t *src, uint64_t *dst, int64_t count);   /* [count][ns][N] -> [count][nb][N] */
+int tfhe_bfv_contract(tfhe_bfv_plan *plan, const uint64_t *src, uint64_t *dst, int64_t count); /* [count][nb][N] -> [count][ns][N] */
+/* c1*c2 followed by keyswitch(evk, ·) on the small ring (the BASELINE.json "ciphertext-mul +
+ * relinearize" unit): out [batch][2][ns][N].  The key ring is ℛ itself (special == 0), which must be
+ * limbs 0..ns-1 of the small ctx; evk: [n_digits][2][ns][N]. */
+int tfhe_bfv_mul_relin(tfhe_bfv_plan *plan, const uint64_t *evk, int n_digits, const uint64_t *c1, const uint64_t *c2, uint64_t *out, int64_t batch);
+/* ciphertexts processed per internal chunk (workspace = chunk * 7 * nb * N * 8 bytes); 0 = default */
+int tfhe_bfv_plan_set_chunk(tfhe_bfv_plan *plan, int chunk);
+
+/* ---- measurement hooks (bench.py): HIP events on the ctx stream --------------------------------
+ * While enabled, every NTT kernel launch is bracketed by a pair of events; read returns the number of
+ * launches, the number of limb-polynomials transformed and the summed kernel time, then resets. */
+int tfhe_prof_enable(tfhe_ctx *ctx, int on);
+int tfhe_prof_read(tfhe_ctx *ctx, int64_t *launches, int64_t *limb_polys, double *total_ms);
+int tfhe_event_create(void **ev);
+int tfhe_event_destroy(void *ev);
+int tfhe_event_record(tfhe_ctx *ctx, void *ev);
+int tfhe_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOYFHE_HIP_H */

@@ -1,0 +1,149 @@
+// tests/emul/emul.cpp -- CPU emulation of the HIP kernels' per-thread bodies.
+//
+// TEST INFRASTRUCTURE ONLY: never loaded by the product package (toyfhe.jl_amd/), which fails loudly
+// without its HIP library.  There is no GPU in the build container, so this file runs the very same
+// device headers (ntt_core.h, conv_core.h, bfv_core.h) on the host -- one loop iteration per thread
+// id, one loop boundary per __syncthreads() -- to check index logic, lazy-range bounds and the exact
+// base-conversion slow path against the oracle before a kernel ever reaches the MI355X.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define TFHE_EMUL_COUNT_SLOW 1
+static long g_slow_hits = 0;
+#include "../../toyfhe.jl_amd/csrc/bfv_tables.h"
+#include "../../toyfhe.jl_amd/csrc/ntt_tables.h"
+
+namespace {
+
+constexpr int pass_k_fwd(int logb, int s0) { return (logb - s0) >= 4 ? 4 : (logb - s0); }
+constexpr int pass_k_inv(int s_end) { return (s_end % 4) ? (s_end % 4) : 4; }
+
+template <int LOGB, int LOGT, int S0>
+void fwd_sched(u64* lds, const u64* gsrc, u64* gdst, const twd_t* W, u64 q, u32 pre, int x, u32 sbrev) {
+    constexpr int K = pass_k_fwd(LOGB, S0);
+    constexpr bool LAST = (S0 + K == LOGB);
+    for (u32 tid = 0; tid < (1u << LOGT); tid++)
+        ntt_fwd_pass<LOGB, LOGT, S0, K, S0 == 0, LAST>(lds, gsrc, gdst, W, q, tid, pre, x, sbrev);
+    if constexpr (!LAST) fwd_sched<LOGB, LOGT, S0 + K>(lds, gsrc, gdst, W, q, pre, x, sbrev);
+}
+template <int LOGB, int LOGT, int SEND, bool SCALE>
+void inv_sched(u64* lds, const u64* gsrc, u64* gdst, const ntt_limb_t& L, u32 pre, int x, u32 sbrev) {
+    constexpr int K = pass_k_inv(SEND);
+    constexpr int S0 = SEND - K;
+    for (u32 tid = 0; tid < (1u << LOGT); tid++)
+        ntt_inv_pass<LOGB, LOGT, S0, K, SEND == LOGB, S0 == 0, SCALE>(lds, gsrc, gdst, L, tid, pre, x, sbrev);
+    if constexpr (S0 != 0) inv_sched<LOGB, LOGT, S0, SCALE>(lds, gsrc, gdst, L, pre, x, sbrev);
+}
+
+template <int LOGB>
+void block_fwd(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
+    std::vector<u64> lds(lds_words(LOGB));
+    for (u32 sb = 0; sb < (1u << x); sb++)
+        fwd_sched<LOGB, LOGB - 4, 0>(lds.data(), src + ((size_t)sb << LOGB), dst, L.W, L.q, (1u << x) + sb, x, brev_bits(sb, x));
+}
+template <int LOGB>
+void block_inv(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
+    std::vector<u64> lds(lds_words(LOGB));
+    for (u32 sb = 0; sb < (1u << x); sb++) {
+        if (x == 0) inv_sched<LOGB, LOGB - 4, LOGB, true>(lds.data(), src, dst, L, 1u, 0, 0u);
+        else inv_sched<LOGB, LOGB - 4, LOGB, false>(lds.data(), src, dst + ((size_t)sb << LOGB), L, (1u << x) + sb, x, brev_bits(sb, x));
+    }
+}
+
+template <int X>
+void top_fwd(const u64* src, u64* dst, const ntt_limb_t& L, int logn) {
+    const u64 stride = (u64)1 << (logn - X);
+    for (u64 col = 0; col < stride; col++) ntt_fwd_top<X>(src, dst, L.W, L.q, col, stride);
+}
+template <int X>
+void top_inv(const u64* src, u64* dst, const ntt_limb_t& L, int logn) {
+    const u64 stride = (u64)1 << (logn - X);
+    for (u64 col = 0; col < stride; col++) ntt_inv_top<X>(src, dst, L, col, stride);
+}
+
+}  // namespace
+
+extern "C" {
+
+// one limb-polynomial transform; variant 0 = register-blocked path (logn >= 10), 1 = generic radix-2.
+// returns 0, -1 on bad psi, -2 on unsupported size
+int emul_ntt(int logn, uint64_t q, uint64_t psi, int inverse, int variant, const uint64_t* src, uint64_t* dst) {
+    const int64_t N = 1ll << logn;
+    if (!psi) psi = hostmath::minimal_primitive_root(q, 2 * (u64)N);
+    std::vector<twd_t> W, Wi;
+    ntt_limb_t L;
+    if (build_ntt_tables(N, q, psi, W, Wi, &L)) return -1;
+    if (variant == 1 || logn < 10) {
+        if (logn > 14) return -2;
+        std::vector<u64> lds((size_t)N);
+        if (!inverse) {
+            for (int64_t i = 0; i < N; i++) lds[i] = src[i];
+            for (int s = 0; s < logn; s++)
+                for (u32 b = 0; b < (u32)(N / 2); b++) ntt_generic_fwd_stage(lds.data(), L.W, L.q, logn, s, b);
+            for (int64_t i = 0; i < N; i++) dst[i] = csub(csub(lds[brev_bits((u32)i, logn)], 2 * q), q);
+        } else {
+            for (int64_t i = 0; i < N; i++) lds[brev_bits((u32)i, logn)] = src[i];
+            for (int s = logn - 1; s >= 0; s--)
+                for (u32 b = 0; b < (u32)(N / 2); b++) ntt_generic_inv_stage(lds.data(), L, logn, s, b);
+            for (int64_t i = 0; i < N; i++) dst[i] = csub(lds[i], q);
+        }
+        return 0;
+    }
+    std::vector<u64> in(src, src + N), tmp((size_t)N), out((size_t)N);
+    if (logn <= 14) {
+        switch (logn) {
+#define C_(LB) case LB: if (inverse) block_inv<LB>(in.data(), out.data(), L, 0); else block_fwd<LB>(in.data(), out.data(), L, 0); break;
+            C_(10) C_(11) C_(12) C_(13) C_(14)
+#undef C_
+        }
+    } else {
+        const int x = logn - 14;
+        if (x > 3) return -2;
+        if (!inverse) {
+            if (x == 1) top_fwd<1>(in.data(), tmp.data(), L, logn); else if (x == 2) top_fwd<2>(in.data(), tmp.data(), L, logn); else top_fwd<3>(in.data(), tmp.data(), L, logn);
+            block_fwd<14>(tmp.data(), out.data(), L, x);
+        } else {
+            block_inv<14>(in.data(), tmp.data(), L, x);
+            if (x == 1) top_inv<1>(tmp.data(), out.data(), L, logn); else if (x == 2) top_inv<2>(tmp.data(), out.data(), L, logn); else top_inv<3>(tmp.data(), out.data(), L, logn);
+        }
+    }
+    memcpy(dst, out.data(), N * 8);
+    return 0;
+}
+
+// exact conversion of `count` coefficients: res [count][k] -> out [count][m]; returns slow-path hits
+long emul_conv(const uint64_t* a, int k, const uint64_t* t, int m, int centred, const uint64_t* res, uint64_t* out, long count) {
+    conv_host_t H;
+    build_conv_host(std::vector<u64>(a, a + k), std::vector<u64>(t, t + m), &H);
+    g_slow_hits = 0;
+    std::vector<u64> xi(k);
+    for (long c = 0; c < count; c++) {
+        for (int j = 0; j < k; j++) xi[j] = res[c * k + j];
+        const u32 alpha = conv_prepare(H.tab, xi.data(), 1, centred != 0);
+        for (int i = 0; i < m; i++) out[c * m + i] = conv_eval(H.tab, xi.data(), 1, i, alpha, centred != 0);
+    }
+    return g_slow_hits;
+}
+
+// BFV expand / contract on [count][limbs][N] buffers; returns 0 or the table-construction error code
+int emul_bfv(const uint64_t* qs, int ns, const uint64_t* pb, int nb, uint64_t t, int contract, int64_t N,
+             const uint64_t* src, uint64_t* dst, long count, long* slow_hits) {
+    bfv_host_t* H = new bfv_host_t();
+    std::string err;
+    int rc = build_bfv_host(std::vector<u64>(qs, qs + ns), std::vector<u64>(pb, pb + nb), t, H, &err);
+    if (rc) { delete H; return rc; }
+    g_slow_hits = 0;
+    std::vector<u64> xi(nb + ns), zb(nb), rb(ns);
+    for (long p = 0; p < count; p++)
+        for (int64_t k = 0; k < N; k++) {
+            if (!contract) bfv_expand_coeff(H->tab, src + p * ns * N + k, N, dst + p * nb * N + k, N, xi.data(), 1);
+            else bfv_contract_coeff(H->tab, src + p * nb * N + k, N, dst + p * ns * N + k, N, xi.data(), zb.data(), rb.data(), 1);
+        }
+    if (slow_hits) *slow_hits = g_slow_hits;
+    delete H;
+    return 0;
+}
+
+}  // extern "C"

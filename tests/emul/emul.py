@@ -1,0 +1,59 @@
+"""ctypes binding of tests/emul/libemul.so (CPU emulation of the HIP kernel bodies; tests only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+u64p = C.POINTER(C.c_uint64)
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-C", _HERE, "libemul.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(_HERE, "libemul.so"))
+        L.emul_ntt.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, u64p, u64p]
+        L.emul_conv.restype = C.c_long
+        L.emul_conv.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_int, u64p, u64p, C.c_long]
+        L.emul_bfv.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_uint64, C.c_int, C.c_int64, u64p, u64p, C.c_long,
+                               C.POINTER(C.c_long)]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(u64p)
+
+
+def ntt(a, q, psi=0, inverse=False, variant=0):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.empty_like(a)
+    rc = lib().emul_ntt(int(a.size).bit_length() - 1, int(q), int(psi), int(inverse), int(variant), _p(a), _p(out))
+    if rc:
+        raise RuntimeError(f"emul_ntt rc={rc}")
+    return out
+
+
+def conv(a, t, res, centred):
+    a = np.array(a, dtype=np.uint64); t = np.array(t, dtype=np.uint64)
+    res = np.ascontiguousarray(res, dtype=np.uint64)
+    out = np.empty((res.shape[0], len(t)), dtype=np.uint64)
+    slow = lib().emul_conv(_p(a), len(a), _p(t), len(t), int(centred), _p(res), _p(out), res.shape[0])
+    return out, slow
+
+
+def bfv(qs, pb, t, src, N, contract):
+    qs_a = np.array(qs, dtype=np.uint64); pb_a = np.array(pb, dtype=np.uint64)
+    src = np.ascontiguousarray(src, dtype=np.uint64)
+    nin, nout = (len(pb), len(qs)) if contract else (len(qs), len(pb))
+    count = src.size // (nin * N)
+    out = np.empty((count, nout, N), dtype=np.uint64)
+    slow = C.c_long(0)
+    rc = lib().emul_bfv(_p(qs_a), len(qs), _p(pb_a), len(pb), int(t), int(contract), N, _p(src), _p(out), count,
+                        C.byref(slow))
+    if rc:
+        raise RuntimeError(f"emul_bfv rc={rc}")
+    return out, slow.value

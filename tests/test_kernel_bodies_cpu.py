@@ -1,0 +1,147 @@
+"""The HIP kernels' per-thread bodies (toyfhe.jl_amd/csrc/*_core.h), run on the CPU by
+tests/emul/ one thread id at a time, against the oracle.  This checks index logic, lazy-range
+bounds and the exact-conversion slow path without a GPU; the GPU tests (-m gpu) then check the
+real kernels through the C ABI."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import ref_cpu, spec
+from tests.emul import emul
+
+
+def _chain(bits, n, N):
+    return spec.prime_chain(2**bits + 1, n, N)
+
+
+@pytest.mark.parametrize("logn", [1, 2, 5, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("bits", [30, 50, 61])
+def test_ntt_bodies_match_oracle(logn, bits):
+    N = 1 << logn
+    q = _chain(bits, 1, N)[0]
+    ctx = ref_cpu.RefCtx(N, [q])
+    rng = np.random.default_rng(logn * 100 + bits)
+    a = rng.integers(0, q, size=N, dtype=np.uint64)
+    a[0] = q - 1; a[-1] = 0   # range edges
+    want = ctx.nntt(a.reshape(1, 1, N)).reshape(N)
+    for variant in ((0, 1) if logn >= 10 else (1,)):
+        got = emul.ntt(a, q, variant=variant)
+        assert np.array_equal(got, want), (logn, bits, variant)
+        back = emul.ntt(want, q, inverse=True, variant=variant)
+        assert np.array_equal(back, a), (logn, bits, variant)
+
+
+@pytest.mark.parametrize("logn", [15, 16])
+def test_ntt_bodies_large_n(logn):
+    N = 1 << logn
+    q = _chain(50, 1, N)[0]
+    ctx = ref_cpu.RefCtx(N, [q])
+    rng = np.random.default_rng(logn)
+    a = rng.integers(0, q, size=N, dtype=np.uint64)
+    want = ctx.nntt(a.reshape(1, 1, N)).reshape(N)
+    assert np.array_equal(emul.ntt(a, q), want)
+    assert np.array_equal(emul.ntt(want, q, inverse=True), a)
+
+
+def test_ntt_bodies_explicit_psi_and_max_modulus():
+    # explicit (non-minimal) psi: cryptparams.jl:25; and a prime just below 2^62 (lazy range 4q < 2^64)
+    q, N, psi = 1152921504606830593, 2048, 811032584449645127
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, q, size=N, dtype=np.uint64)
+    want = np.array(spec.nntt([int(x) for x in a], q, psi), dtype=np.uint64)
+    assert np.array_equal(emul.ntt(a, q, psi=psi), want)
+    N = 4096
+    q = 2**62 - 2 * N + 1
+    while not (spec.is_prime(q)):
+        q -= 2 * N
+    a = rng.integers(0, q, size=N, dtype=np.uint64); a[:4] = q - 1
+    ctx = ref_cpu.RefCtx(N, [q])
+    want = ctx.nntt(a.reshape(1, 1, N)).reshape(N)
+    assert np.array_equal(emul.ntt(a, q), want)
+    assert np.array_equal(emul.ntt(want, q, inverse=True), a)
+    with pytest.raises(RuntimeError):
+        emul.ntt(a, q, psi=5)
+
+
+def _conv_ref(a, t, res, centred):
+    A = 1
+    for x in a:
+        A *= x
+    out = []
+    for r in res:
+        x = spec.rns_to_int([int(v) for v in r], a)
+        if centred:
+            x = spec.centred(x, A)
+        out.append([x % ti for ti in t])
+    return np.array(out, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("bits,k,m", [(50, 8, 9), (50, 9, 8), (40, 3, 2), (61, 4, 5), (30, 17, 3), (50, 2, 4)])
+@pytest.mark.parametrize("centred", [False, True])
+def test_exact_conversion_random_and_edges(bits, k, m, centred):
+    N = 64
+    ch = _chain(bits, k + m, N)
+    a, t = ch[:k], ch[k:]
+    A = 1
+    for x in a:
+        A *= x
+    rng = random.Random(bits * k + m)
+    vals = [rng.randrange(A) for _ in range(200)]
+    # structured values that sit on the alpha decision boundary / centring boundary
+    vals += [0, 1, 2, A - 1, A - 2, A // 2, A // 2 + 1, A // 2 - 1, A // 2 + 2, 12345, A - 12345,
+             (A // 2 + 1 + 5) % A, a[0], A // a[0], A - A // a[0]]
+    res = np.array([[v % x for x in a] for v in vals], dtype=np.uint64)
+    got, slow = emul.conv(a, t, res, centred)
+    assert np.array_equal(got, _conv_ref(a, t, res, centred))
+    assert slow > 0  # the structured values force the exact multi-word branch
+
+
+def test_exact_conversion_target_equals_source():
+    N = 64
+    ch = _chain(50, 5, N)
+    a, t = ch[:3], [ch[1], ch[3], ch[0], ch[4]]
+    rng = random.Random(9)
+    A = a[0] * a[1] * a[2]
+    vals = [rng.randrange(A) for _ in range(50)] + [0, 1, A - 1, A // 2, A // 2 + 1]
+    res = np.array([[v % x for x in a] for v in vals], dtype=np.uint64)
+    for centred in (False, True):
+        got, _ = emul.conv(a, t, res, centred)
+        assert np.array_equal(got, _conv_ref(a, t, res, centred))
+
+
+@pytest.mark.parametrize("mode", ["superset", "disjoint"])
+@pytest.mark.parametrize("bits,ns,nextra", [(50, 3, 4), (40, 2, 3), (60, 2, 3)])
+def test_bfv_expand_contract_bodies(mode, bits, ns, nextra):
+    N, t = 32, 65537
+    ch = _chain(bits, ns + nextra + ns, N)
+    qs = ch[:ns]
+    pb = (ch[: ns + nextra] if mode == "superset" else ch[ns: 2 * ns + nextra + 1])
+    if mode == "superset":
+        pb = pb[::-1]  # ℛbig limb order is arbitrary: put the shared primes last
+    cs, cb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, pb)
+    small, big = spec.Ring(N, qs), spec.Ring(N, pb)
+    rng = np.random.default_rng(bits + ns)
+    a = np.stack([rng.integers(0, q, size=(5, N), dtype=np.uint64) for q in qs], axis=1)
+    for k, x in enumerate([0, 1, small.Q - 1, small.Q // 2, small.Q // 2 + 1, 7, small.Q - 7]):
+        for l, q in enumerate(qs):
+            a[0, l, k] = x % q
+    got, _ = emul.bfv(qs, pb, t, a, N, contract=False)
+    assert np.array_equal(got, ref_cpu.switch(cs, cb, a))
+    y = np.stack([rng.integers(0, p, size=(6, N), dtype=np.uint64) for p in pb], axis=1)
+    tinv = pow(t, -1, big.Q)
+    edges = [0, 1, big.Q - 1, big.Q // 2, big.Q // 2 + 1, small.Q // 2, small.Q // 2 + 1, small.Q, small.Q - 1,
+             3 * small.Q + small.Q // 2, 3 * small.Q + small.Q // 2 + 1, big.Q - small.Q // 2, big.Q - small.Q // 2 - 1]
+    for k, x in enumerate(edges):
+        for l, p in enumerate(pb):
+            y[0, l, k] = (x * tinv) % big.Q % p
+    got, slow = emul.bfv(qs, pb, t, y, N, contract=True)
+    assert np.array_equal(got, ref_cpu.contract(cb, cs, t, y))
+    assert slow > 0
+
+
+def test_bfv_bodies_reject_partial_overlap():
+    N = 32
+    ch = _chain(50, 6, N)
+    with pytest.raises(RuntimeError):
+        emul.bfv(ch[:3], ch[1:6], 65537, np.zeros((1, 3, N), dtype=np.uint64), N, contract=False)

@@ -1,0 +1,90 @@
+// modarith.h -- 64-bit modular arithmetic for RNS limbs q < 2^62 (the device stand-in for
+// GaloisFields.PrimeField arithmetic, reference call sites src/pow2_cyc_rings.jl:3,15 and the
+// limb-wise ops of src/crt.jl:120-134).
+//
+// Everything here is plain integer code usable from HIP device code and (for the CPU index-logic
+// emulation under tests/emul/) from host C++.  No MFMA: this is integer modular work; the scarce
+// resources are the 32-bit integer multiplier and HBM/LDS bandwidth.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>
+#define TFHE_HD __host__ __device__ __forceinline__
+#else
+#define TFHE_HD inline
+#endif
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef unsigned __int128 u128;
+
+struct tw_t {  // a multiplier constant w (< q) with its Shoup companion floor(w * 2^64 / q)
+    u64 w, wp;
+};
+
+TFHE_HD u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((u128)a * b) >> 64);
+#endif
+}
+
+// x * w mod q for a precomputed (w, wp); x is ANY u64, result in [0, 2q)  (Harvey/Shoup lazy form)
+TFHE_HD u64 shoup_lazy(u64 x, tw_t t, u64 q) { return x * t.w - mulhi64(x, t.wp) * q; }
+// same, fully reduced to [0, q)
+TFHE_HD u64 shoup_full(u64 x, tw_t t, u64 q) {
+    u64 r = shoup_lazy(x, t, q);
+    return r >= q ? r - q : r;
+}
+
+TFHE_HD u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }  // conditional subtract
+TFHE_HD u64 addmod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
+TFHE_HD u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+TFHE_HD u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }
+
+// Per-modulus Barrett data for products of two variable operands.
+//   k  = bit length of q (q < 2^62), sh = k - 2,  mu = floor(2^(k+62) / q) < 2^63.
+// For z < 2^(k+62):  qh = mulhi64(z >> sh, mu) satisfies z/q - 2.5 < qh <= z/q, so
+// z - qh*q lies in [0, 4q) and fits a u64; two conditional subtractions finish it.
+struct barrett_t {
+    u64 q, mu;
+    u32 sh;
+};
+
+TFHE_HD u64 barrett_reduce128(u64 zlo, u64 zhi, const barrett_t& m) {
+    // z >> sh, sh in [0, 60]; callers guarantee z < 2^(sh+64)
+    u64 z1 = m.sh ? ((zlo >> m.sh) | (zhi << (64 - m.sh))) : zlo;
+    u64 qh = mulhi64(z1, m.mu);
+    u64 r = zlo - qh * m.q;
+    r = csub(r, 2 * m.q);
+    return csub(r, m.q);
+}
+
+TFHE_HD u64 mulmod(u64 a, u64 b, const barrett_t& m) {
+    u64 lo = a * b, hi = mulhi64(a, b);
+    return barrett_reduce128(lo, hi, m);
+}
+
+// 128-bit accumulator for lazy sums of products (reduced once by barrett_reduce128)
+struct acc128 {
+    u64 lo, hi;
+};
+TFHE_HD void acc_mac(acc128& a, u64 x, u64 y) {
+    u64 lo = x * y, hi = mulhi64(x, y);
+    u64 s = a.lo + lo;
+    a.hi += hi + (s < lo);
+    a.lo = s;
+}
+
+// bit reversal of the low `bits` bits
+TFHE_HD u32 brev_bits(u32 x, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+    u32 r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}

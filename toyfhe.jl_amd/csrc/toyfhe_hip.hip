@@ -1,0 +1,583 @@
+// toyfhe_hip.hip -- context management and the C ABI of libtoyfhe_hip.so (see include/toyfhe_hip.h).
+// gfx950 only.  No torch types, no oracle code, no CPU fallback: every compute entry point launches
+// HIP kernels and fails with TFHE_E_HIP if the device is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/toyfhe_hip.h"
+#include "bfv_tables.h"
+#include "host_math.h"
+#include "kernels.h"
+#include "ntt_tables.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(TFHE_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+struct prof_pair {
+    hipEvent_t a, b;
+    int64_t limb_polys;
+};
+
+}  // namespace
+
+struct tfhe_ctx {
+    int64_t N = 0;
+    int logN = 0, L = 0;
+    std::vector<u64> q, psi;
+    std::vector<ntt_limb_t> limbs_host;
+    ntt_limb_t* limbs_dev = nullptr;
+    std::vector<twd_t*> tabs;  // device twiddle tables (W, Winv per limb)
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int variant = 0;
+    // workspace (grown on demand, reused)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    // profiling
+    bool prof = false;
+    std::vector<prof_pair> prof_pairs;
+};
+
+namespace {
+
+int ensure_ws(tfhe_ctx* c, size_t bytes, void** out) {
+    if (bytes > c->ws_bytes) {
+        if (c->ws) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipFree(c->ws));
+            c->ws = nullptr;
+            c->ws_bytes = 0;
+        }
+        hipError_t e = hipMalloc(&c->ws, bytes);
+        if (e != hipSuccess) return fail(TFHE_E_NOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        c->ws_bytes = bytes;
+    }
+    *out = c->ws;
+    return TFHE_OK;
+}
+
+int make_sel(const tfhe_ctx* c, int limbs, const int32_t* idx, limb_sel_t* sel) {
+    if (limbs < 1 || limbs > TFHE_MAX_LIMBS) return fail(TFHE_E_BADARG, "limbs=%d out of range [1,%d]", limbs, TFHE_MAX_LIMBS);
+    sel->n = limbs;
+    for (int j = 0; j < limbs; j++) {
+        const int v = idx ? idx[j] : j;
+        if (v < 0 || v >= c->L) return fail(TFHE_E_LEVEL_MISMATCH, "limb_idx[%d]=%d outside the ring's %d moduli", j, v, c->L);
+        sel->idx[j] = v;
+    }
+    return TFHE_OK;
+}
+
+template <int LOGB>
+constexpr int logt_for() { return LOGB - 4; }  // 16 elements per thread
+
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return TFHE_OK;
+}
+
+void prof_begin(tfhe_ctx* c, int64_t limb_polys) {
+    if (!c->prof) return;
+    prof_pair p;
+    hipEventCreate(&p.a);
+    hipEventCreate(&p.b);
+    p.limb_polys = limb_polys;
+    hipEventRecord(p.a, c->stream);
+    c->prof_pairs.push_back(p);
+}
+void prof_end(tfhe_ctx* c) {
+    if (!c->prof) return;
+    hipEventRecord(c->prof_pairs.back().b, c->stream);
+}
+
+template <int LOGB>
+int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x) {
+    constexpr int LOGT = logt_for<LOGB>();
+    const size_t lds = (size_t)lds_words(LOGB) * 8;
+    auto kern = k_ntt_fwd_block<LOGB, LOGT>;
+    static bool attr_set = false;
+    if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
+    prof_begin(c, rows);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(rows << x)), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x);
+    prof_end(c);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+template <int LOGB>
+int launch_block_inv(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x) {
+    constexpr int LOGT = logt_for<LOGB>();
+    const size_t lds = (size_t)lds_words(LOGB) * 8;
+    auto kern = k_ntt_inv_block<LOGB, LOGT>;
+    static bool attr_set = false;
+    if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
+    prof_begin(c, rows);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(rows << x)), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x);
+    prof_end(c);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
+int launch_generic(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel) {
+    const size_t lds = (size_t)c->N * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = set_lds(k_ntt_fwd_generic, 128 * 1024);
+        if (rc) return rc;
+        rc = set_lds(k_ntt_inv_generic, 128 * 1024);
+        if (rc) return rc;
+        attr_set = true;
+    }
+    const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, c->N / 2));
+    prof_begin(c, rows);
+    if (inverse)
+        hipLaunchKernelGGL(k_ntt_inv_generic, dim3((unsigned)rows), dim3(threads), lds, c->stream, src, dst, c->limbs_dev, sel, c->logN);
+    else
+        hipLaunchKernelGGL(k_ntt_fwd_generic, dim3((unsigned)rows), dim3(threads), lds, c->stream, src, dst, c->limbs_dev, sel, c->logN);
+    prof_end(c);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
+// forward / inverse transform of `rows` limb-polynomials; src == dst allowed
+int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel) {
+    if (rows == 0) return TFHE_OK;
+    if (rows < 0 || (rows << std::max(0, c->logN - 14)) > 0x7fffffffll) return fail(TFHE_E_BADARG, "bad polynomial count");
+    const int n = c->logN;
+    const bool use_block = (c->variant == 0 && n >= 10) || n > 14;
+    if (!use_block) return launch_generic(c, inverse, src, dst, rows, sel);
+    if (n <= 14) {
+        switch (n) {
+#define CASE_(LB)                                                                                              \
+    case LB: return inverse ? launch_block_inv<LB>(c, src, dst, rows, sel, 0) : launch_block_fwd<LB>(c, src, dst, rows, sel, 0);
+            CASE_(10) CASE_(11) CASE_(12) CASE_(13) CASE_(14)
+#undef CASE_
+        }
+    }
+    // N > 2^14: x top stages on global memory + 2^14 blocks; needs an out-of-place intermediate
+    const int x = n - 14;
+    if (x > 3) return fail(TFHE_E_UNSUPPORTED, "N = 2^%d not supported (max 2^17)", n);
+    void* tmp = nullptr;
+    int rc = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
+    if (rc) return rc;
+    u64* t = (u64*)tmp;
+    const dim3 tg((unsigned)((((c->N >> x) + 255) / 256) * rows));
+    if (!inverse) {
+        prof_begin(c, 0);
+        switch (x) {
+            case 1: hipLaunchKernelGGL(k_ntt_fwd_top<1>, tg, dim3(256), 0, c->stream, src, t, c->limbs_dev, sel, n); break;
+            case 2: hipLaunchKernelGGL(k_ntt_fwd_top<2>, tg, dim3(256), 0, c->stream, src, t, c->limbs_dev, sel, n); break;
+            default: hipLaunchKernelGGL(k_ntt_fwd_top<3>, tg, dim3(256), 0, c->stream, src, t, c->limbs_dev, sel, n); break;
+        }
+        prof_end(c);
+        HIP_TRY(hipGetLastError());
+        return launch_block_fwd<14>(c, t, dst, rows, sel, x);
+    }
+    rc = launch_block_inv<14>(c, src, t, rows, sel, x);
+    if (rc) return rc;
+    prof_begin(c, 0);
+    switch (x) {
+        case 1: hipLaunchKernelGGL(k_ntt_inv_top<1>, tg, dim3(256), 0, c->stream, t, dst, c->limbs_dev, sel, n); break;
+        case 2: hipLaunchKernelGGL(k_ntt_inv_top<2>, tg, dim3(256), 0, c->stream, t, dst, c->limbs_dev, sel, n); break;
+        default: hipLaunchKernelGGL(k_ntt_inv_top<3>, tg, dim3(256), 0, c->stream, t, dst, c->limbs_dev, sel, n); break;
+    }
+    prof_end(c);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
+template <int OP>
+int run_pointwise(tfhe_ctx* c, const u64* a, const u64* b, const u64* acc, u64* dst, int64_t count, int limbs,
+                  const int32_t* idx, const scal_arg_t* sc) {
+    if (!c) return fail(TFHE_E_BADARG, "null context");
+    limb_sel_t sel;
+    int rc = make_sel(c, limbs, idx, &sel);
+    if (rc) return rc;
+    if (count == 0) return TFHE_OK;
+    if (count < 0 || count * limbs > 0x7fffffffll) return fail(TFHE_E_BADARG, "bad polynomial count");
+    scal_arg_t s0;
+    if (!sc) { memset(&s0, 0, sizeof s0); sc = &s0; }
+    hipLaunchKernelGGL(k_pointwise<OP>, dim3((unsigned)(count * limbs)), dim3(256), 0, c->stream, a, b, acc, dst,
+                       c->limbs_dev, sel, *sc, (u32)c->N);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* tfhe_last_error(void) { return g_err.c_str(); }
+
+int tfhe_device_count(int* n) {
+    if (!n) return fail(TFHE_E_BADARG, "null out pointer");
+    hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess) { *n = 0; return fail(TFHE_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return TFHE_OK;
+}
+int tfhe_set_device(int dev) { HIP_TRY(hipSetDevice(dev)); return TFHE_OK; }
+
+int tfhe_ctx_create(int64_t N, int L, const uint64_t* q, const uint64_t* psi, tfhe_ctx** out) {
+    using namespace hostmath;
+    if (!out) return fail(TFHE_E_BADARG, "null out pointer");
+    *out = nullptr;
+    if (N < 2 || (N & (N - 1)) || N > (1 << 17)) return fail(TFHE_E_BADARG, "N=%lld must be a power of two in [2, 2^17]", (long long)N);
+    if (L < 1 || L > TFHE_MAX_LIMBS || !q) return fail(TFHE_E_BADARG, "L=%d out of range [1,%d]", L, TFHE_MAX_LIMBS);
+    int logN = 0;
+    while ((1ll << logN) < N) logN++;
+    for (int l = 0; l < L; l++) {
+        if (q[l] < 3 || q[l] >= (1ull << 62) || !is_prime(q[l])) return fail(TFHE_E_BADARG, "q[%d]=%llu is not a prime below 2^62", l, (unsigned long long)q[l]);
+        if ((q[l] - 1) % (2 * (u64)N)) return fail(TFHE_E_BADARG, "q[%d]=%llu: 2N does not divide q-1 (no 2N-th root of unity; the reference's naive ψ=0 path is host-only)", l, (unsigned long long)q[l]);
+        for (int m = 0; m < l; m++)
+            if (q[m] == q[l]) return fail(TFHE_E_BADARG, "q[%d] repeats q[%d]", l, m);
+    }
+    tfhe_ctx* c = new tfhe_ctx();
+    c->N = N; c->logN = logN; c->L = L;
+    c->q.assign(q, q + L);
+    c->psi.resize(L);
+    c->limbs_host.resize(L);
+    std::vector<twd_t> W, Wi;
+    for (int l = 0; l < L; l++) {
+        const u64 ql = q[l];
+        u64 p = (psi && psi[l]) ? psi[l] : minimal_primitive_root(ql, 2 * (u64)N);
+        ntt_limb_t& LL = c->limbs_host[l];
+        if (build_ntt_tables(N, ql, p, W, Wi, &LL) != 0) {  // pow2_cyc_rings.jl:31,61 (+ primitivity: psi^N == -1)
+            tfhe_ctx_destroy(c);
+            return fail(TFHE_E_BADARG, "psi[%d]=%llu is not a primitive 2N-th root of unity mod q[%d]", l, (unsigned long long)p, l);
+        }
+        c->psi[l] = p;
+        twd_t *dW = nullptr, *dWi = nullptr;
+        if (hipMalloc(&dW, N * sizeof(twd_t)) != hipSuccess || hipMalloc(&dWi, N * sizeof(twd_t)) != hipSuccess) {
+            tfhe_ctx_destroy(c);
+            return fail(TFHE_E_HIP, "hipMalloc of twiddle tables failed (no usable HIP device?)");
+        }
+        c->tabs.push_back(dW); c->tabs.push_back(dWi);
+        if (hipMemcpy(dW, W.data(), N * sizeof(twd_t), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dWi, Wi.data(), N * sizeof(twd_t), hipMemcpyHostToDevice) != hipSuccess) {
+            tfhe_ctx_destroy(c);
+            return fail(TFHE_E_HIP, "hipMemcpy of twiddle tables failed");
+        }
+        LL.W = dW;
+        LL.Winv = dWi;
+    }
+    if (hipMalloc(&c->limbs_dev, L * sizeof(ntt_limb_t)) != hipSuccess) { tfhe_ctx_destroy(c); return fail(TFHE_E_HIP, "hipMalloc failed"); }
+    hipMemcpy(c->limbs_dev, c->limbs_host.data(), L * sizeof(ntt_limb_t), hipMemcpyHostToDevice);
+    if (hipStreamCreate(&c->stream) != hipSuccess) { tfhe_ctx_destroy(c); return fail(TFHE_E_HIP, "hipStreamCreate failed"); }
+    c->own_stream = true;
+    *out = c;
+    return TFHE_OK;
+}
+
+int tfhe_ctx_destroy(tfhe_ctx* c) {
+    if (!c) return TFHE_OK;
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto* t : c->tabs) hipFree(t);
+    if (c->limbs_dev) hipFree(c->limbs_dev);
+    if (c->ws) hipFree(c->ws);
+    for (auto& p : c->prof_pairs) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return TFHE_OK;
+}
+
+int tfhe_ctx_psi(const tfhe_ctx* c, uint64_t* out) {
+    if (!c || !out) return fail(TFHE_E_BADARG, "null argument");
+    memcpy(out, c->psi.data(), c->L * 8);
+    return TFHE_OK;
+}
+int tfhe_ctx_set_stream(tfhe_ctx* c, void* s) {
+    if (!c) return fail(TFHE_E_BADARG, "null context");
+    if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
+    else { HIP_TRY(hipStreamCreate(&c->stream)); c->own_stream = true; }
+    return TFHE_OK;
+}
+int tfhe_ctx_sync(tfhe_ctx* c) {
+    if (!c) return fail(TFHE_E_BADARG, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+int tfhe_ctx_set_ntt_variant(tfhe_ctx* c, int v) {
+    if (!c || v < 0 || v > 1) return fail(TFHE_E_BADARG, "variant must be 0 or 1");
+    c->variant = v;
+    return TFHE_OK;
+}
+
+int tfhe_malloc(size_t bytes, void** p) {
+    if (!p) return fail(TFHE_E_BADARG, "null out pointer");
+    hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? TFHE_E_NOMEM : TFHE_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return TFHE_OK;
+}
+int tfhe_free(void* p) { if (p) HIP_TRY(hipFree(p)); return TFHE_OK; }
+int tfhe_memcpy_h2d(void* d, const void* s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return TFHE_OK; }
+int tfhe_memcpy_d2h(void* d, const void* s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return TFHE_OK; }
+int tfhe_memcpy_d2d(tfhe_ctx* c, void* d, const void* s, size_t n) {
+    if (!c) return fail(TFHE_E_BADARG, "null context");
+    HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream));
+    return TFHE_OK;
+}
+int tfhe_memset(tfhe_ctx* c, void* d, int byte, size_t n) {
+    if (!c) return fail(TFHE_E_BADARG, "null context");
+    HIP_TRY(hipMemsetAsync(d, byte, n, c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_nntt(tfhe_ctx* c, const uint64_t* src, uint64_t* dst, int64_t count, int limbs, const int32_t* idx) {
+    if (!c || !src || !dst) return fail(TFHE_E_BADARG, "null argument");
+    limb_sel_t sel;
+    int rc = make_sel(c, limbs, idx, &sel);
+    if (rc) return rc;
+    return run_ntt(c, false, src, dst, count * limbs, sel);
+}
+int tfhe_inntt(tfhe_ctx* c, const uint64_t* src, uint64_t* dst, int64_t count, int limbs, const int32_t* idx) {
+    if (!c || !src || !dst) return fail(TFHE_E_BADARG, "null argument");
+    limb_sel_t sel;
+    int rc = make_sel(c, limbs, idx, &sel);
+    if (rc) return rc;
+    return run_ntt(c, true, src, dst, count * limbs, sel);
+}
+
+int tfhe_add(tfhe_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* d, int64_t n, int l, const int32_t* i) { return run_pointwise<OP_ADD>(c, a, b, nullptr, d, n, l, i, nullptr); }
+int tfhe_sub(tfhe_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* d, int64_t n, int l, const int32_t* i) { return run_pointwise<OP_SUB>(c, a, b, nullptr, d, n, l, i, nullptr); }
+int tfhe_neg(tfhe_ctx* c, const uint64_t* a, uint64_t* d, int64_t n, int l, const int32_t* i) { return run_pointwise<OP_NEG>(c, a, nullptr, nullptr, d, n, l, i, nullptr); }
+int tfhe_mul(tfhe_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* d, int64_t n, int l, const int32_t* i) { return run_pointwise<OP_MUL>(c, a, b, nullptr, d, n, l, i, nullptr); }
+int tfhe_mad(tfhe_ctx* c, const uint64_t* acc, const uint64_t* a, const uint64_t* b, uint64_t* d, int64_t n, int l, const int32_t* i) { return run_pointwise<OP_MAD>(c, a, b, acc, d, n, l, i, nullptr); }
+int tfhe_scalar_mul(tfhe_ctx* c, const uint64_t* scal, const uint64_t* a, uint64_t* d, int64_t n, int l, const int32_t* idx) {
+    if (!c || !scal) return fail(TFHE_E_BADARG, "null argument");
+    limb_sel_t sel;
+    int rc = make_sel(c, l, idx, &sel);
+    if (rc) return rc;
+    scal_arg_t sc;
+    memset(&sc, 0, sizeof sc);
+    for (int j = 0; j < l; j++) { const u64 q = c->q[sel.idx[j]]; sc.s[j] = hostmath::make_tw(scal[j] % q, q); }
+    return run_pointwise<OP_SCAL>(c, a, nullptr, nullptr, d, n, l, idx, &sc);
+}
+
+int tfhe_tensor(tfhe_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, int64_t batch, int limbs, const int32_t* idx) {
+    if (!c || !a || !b || !out) return fail(TFHE_E_BADARG, "null argument");
+    limb_sel_t sel;
+    int rc = make_sel(c, limbs, idx, &sel);
+    if (rc) return rc;
+    if (batch == 0) return TFHE_OK;
+    hipLaunchKernelGGL(k_tensor, dim3((unsigned)(batch * limbs)), dim3(256), 0, c->stream, a, b, out, c->limbs_dev, sel, (u32)c->N);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
+static int do_rescale(tfhe_ctx* c, const u64* src, u64* dst, int64_t count, const limb_sel_t& sel) {
+    if (sel.n < 2) return fail(TFHE_E_LEVEL_MISMATCH, "modswitch needs at least 2 limbs");
+    rescale_arg_t ra;
+    memset(&ra, 0, sizeof ra);
+    const u64 ql = c->q[sel.idx[sel.n - 1]];
+    for (int j = 0; j < sel.n - 1; j++) {
+        const u64 qj = c->q[sel.idx[j]];
+        ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(ql % qj, qj), qj);
+    }
+    if (count == 0) return TFHE_OK;
+    hipLaunchKernelGGL(k_rescale, dim3((unsigned)(count * (sel.n - 1))), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, ra, (u32)c->N);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+int tfhe_rescale(tfhe_ctx* c, const uint64_t* src, uint64_t* dst, int64_t count, int limbs, const int32_t* idx) {
+    if (!c || !src || !dst) return fail(TFHE_E_BADARG, "null argument");
+    limb_sel_t sel;
+    int rc = make_sel(c, limbs, idx, &sel);
+    if (rc) return rc;
+    return do_rescale(c, src, dst, count, sel);
+}
+
+int tfhe_select_limbs(tfhe_ctx* c, const uint64_t* src, uint64_t* dst, int64_t count, int src_limbs, const int32_t* which, int nw) {
+    if (!c || !src || !dst || !which) return fail(TFHE_E_BADARG, "null argument");
+    if (nw < 1 || nw > TFHE_MAX_LIMBS) return fail(TFHE_E_BADARG, "bad limb count");
+    limb_sel_t w;
+    w.n = nw;
+    for (int j = 0; j < nw; j++) {
+        if (which[j] < 0 || which[j] >= src_limbs) return fail(TFHE_E_LEVEL_MISMATCH, "which[%d]=%d outside source limbs", j, which[j]);
+        w.idx[j] = which[j];
+    }
+    if (count == 0) return TFHE_OK;
+    hipLaunchKernelGGL(k_select, dim3((unsigned)(count * nw)), dim3(256), 0, c->stream, src, dst, w, src_limbs, (u32)c->N);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
+static int do_galois(tfhe_ctx* c, const u64* src, u64* dst, u64 g, int64_t rows, const limb_sel_t& sel) {
+    if ((g & 1) == 0) return fail(TFHE_E_BADARG, "galois element %llu must be odd", (unsigned long long)g);
+    if (src == dst) return fail(TFHE_E_BADARG, "tfhe_galois cannot run in place");
+    const u64 m = 2 * (u64)c->N;
+    g %= m;
+    u64 ginv = 1;  // inverse modulo 2N by Newton iteration (g odd)
+    for (int i = 0; i < 6; i++) ginv = (ginv * (2 - g * ginv)) & (m - 1);
+    if (rows == 0) return TFHE_OK;
+    hipLaunchKernelGGL(k_galois, dim3((unsigned)rows), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, ginv, (u32)c->N);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+int tfhe_galois(tfhe_ctx* c, const uint64_t* src, uint64_t* dst, uint64_t g, int64_t count, int limbs, const int32_t* idx) {
+    if (!c || !src || !dst) return fail(TFHE_E_BADARG, "null argument");
+    limb_sel_t sel;
+    int rc = make_sel(c, limbs, idx, &sel);
+    if (rc) return rc;
+    return do_galois(c, src, dst, g, count * limbs, sel);
+}
+
+// ---- keyswitch ------------------------------------------------------------------------------------
+static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
+                    u64* acc, u64* dig) {
+    const int nw = special ? level + 1 : level;
+    ks_arg_t A;
+    memset(&A, 0, sizeof A);
+    A.level = level; A.nw = nw; A.special = special; A.polys = polys;
+    A.w.n = nw;
+    for (int j = 0; j < level; j++) A.w.idx[j] = j;
+    if (special) A.w.idx[level] = Lk - 1;  // downswitch_keyelement, modulusraising.jl:43-49
+    const u64 P = c->q[Lk - 1];
+    for (int j = 0; j < level; j++) A.pmul[j] = hostmath::make_tw(special ? P % c->q[j] : 1, c->q[j]);
+    const u32 n = (u32)c->N;
+    hipLaunchKernelGGL(k_ks_init, dim3((unsigned)(batch * 2 * nw)), dim3(256), 0, c->stream, ct, acc, c->limbs_dev, A, n);
+    hipLaunchKernelGGL(k_ks_digits, dim3((unsigned)(batch * level * nw)), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n);
+    HIP_TRY(hipGetLastError());
+    int rc = run_ntt(c, false, acc, acc, batch * 2 * nw, A.w);
+    if (rc) return rc;
+    rc = run_ntt(c, false, dig, dig, batch * level * nw, A.w);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ks_inner, dim3((unsigned)(batch * nw)), dim3(256), 0, c->stream, evk, dig, acc, c->limbs_dev, A, Lk, n);
+    HIP_TRY(hipGetLastError());
+    if (special) {
+        rc = run_ntt(c, true, acc, acc, batch * 2 * nw, A.w);
+        if (rc) return rc;
+        return do_rescale(c, acc, out, batch * 2, A.w);  // keyswitch_contract = modswitch, modulusraising.jl:42
+    }
+    return run_ntt(c, true, acc, out, batch * 2 * nw, A.w);
+}
+
+static int ks_check(tfhe_ctx* c, int Lk, int level, int special, const void* evk, int n_digits, const void* ct, int polys, const void* out, int64_t batch) {
+    if (!c || !evk || !ct || !out) return fail(TFHE_E_BADARG, "null argument");
+    if (polys != 2 && polys != 3) return fail(TFHE_E_BADARG, "keyswitch needs a 2- or 3-element ciphertext (rlwe_she.jl:318), got %d", polys);
+    if (Lk < 1 || Lk > c->L) return fail(TFHE_E_LEVEL_MISMATCH, "key_limbs=%d outside [1,%d]", Lk, c->L);
+    const int maxlevel = special ? Lk - 1 : Lk;
+    if (level < 1 || level > maxlevel) return fail(TFHE_E_LEVEL_MISMATCH, "level=%d outside [1,%d]", level, maxlevel);
+    if (n_digits < level) return fail(TFHE_E_PARAMS_MISMATCH, "evaluation key has %d components, level %d needs %d", n_digits, level, level);
+    if (batch < 0) return fail(TFHE_E_BADARG, "negative batch");
+    return TFHE_OK;
+}
+
+static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
+                          u64 galois, bool rotate) {
+    const int nw = special ? level + 1 : level;
+    const size_t N = (size_t)c->N;
+    // chunk the batch so that the digit tensor stays at a few hundred MiB
+    const size_t per_ct = ((size_t)2 * nw + (size_t)level * nw + (rotate ? (size_t)polys * level : 0)) * N * 8;
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(batch, (int64_t)((512ull << 20) / per_ct)));
+    void* ws = nullptr;
+    // NTT of N > 2^14 uses the context workspace as well: keep ours separate by over-allocating
+    const size_t ntt_tmp = c->logN > 14 ? (size_t)chunk * std::max(2, level) * nw * N * 8 : 0;
+    int rc = ensure_ws(c, ntt_tmp + chunk * per_ct, &ws);
+    if (rc) return rc;
+    u64* base = (u64*)((char*)ws + ntt_tmp);
+    u64* acc = base;
+    u64* dig = acc + (size_t)chunk * 2 * nw * N;
+    u64* rot = dig + (size_t)chunk * level * nw * N;
+    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int64_t nb = std::min(chunk, batch - b0);
+        const u64* cin = ct + (size_t)b0 * polys * level * N;
+        if (rotate) {
+            limb_sel_t s;
+            s.n = level;
+            for (int j = 0; j < level; j++) s.idx[j] = j;
+            rc = do_galois(c, cin, rot, galois, nb * polys * level, s);
+            if (rc) return rc;
+            cin = rot;
+        }
+        rc = ks_chunk(c, Lk, level, special, evk, cin, polys, out + (size_t)b0 * 2 * level * N, nb, acc, dig);
+        if (rc) return rc;
+    }
+    return TFHE_OK;
+}
+
+int tfhe_keyswitch(tfhe_ctx* c, int Lk, int level, int special, const uint64_t* evk, int n_digits, const uint64_t* ct, int polys, uint64_t* out, int64_t batch) {
+    int rc = ks_check(c, Lk, level, special, evk, n_digits, ct, polys, out, batch);
+    if (rc) return rc;
+    return keyswitch_impl(c, Lk, level, special, evk, ct, polys, out, batch, 0, false);
+}
+int tfhe_rotate(tfhe_ctx* c, int Lk, int level, int special, const uint64_t* evk, int n_digits, uint64_t g, const uint64_t* ct, uint64_t* out, int64_t batch) {
+    int rc = ks_check(c, Lk, level, special, evk, n_digits, ct, 2, out, batch);
+    if (rc) return rc;
+    if ((g & 1) == 0) return fail(TFHE_E_BADARG, "galois element must be odd");
+    return keyswitch_impl(c, Lk, level, special, evk, ct, 2, out, batch, g, true);
+}
+
+// ---- profiling / events ---------------------------------------------------------------------------
+int tfhe_prof_enable(tfhe_ctx* c, int on) {
+    if (!c) return fail(TFHE_E_BADARG, "null context");
+    c->prof = on != 0;
+    return TFHE_OK;
+}
+int tfhe_prof_read(tfhe_ctx* c, int64_t* launches, int64_t* limb_polys, double* total_ms) {
+    if (!c) return fail(TFHE_E_BADARG, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int64_t nl = 0, np = 0;
+    double ms = 0;
+    for (auto& p : c->prof_pairs) {
+        float t = 0;
+        hipEventElapsedTime(&t, p.a, p.b);
+        if (p.limb_polys > 0) { nl++; np += p.limb_polys; ms += t; }
+        hipEventDestroy(p.a);
+        hipEventDestroy(p.b);
+    }
+    c->prof_pairs.clear();
+    if (launches) *launches = nl;
+    if (limb_polys) *limb_polys = np;
+    if (total_ms) *total_ms = ms;
+    return TFHE_OK;
+}
+int tfhe_event_create(void** ev) {
+    if (!ev) return fail(TFHE_E_BADARG, "null out pointer");
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *ev = (void*)e;
+    return TFHE_OK;
+}
+int tfhe_event_destroy(void* ev) { if (ev) HIP_TRY(hipEventDestroy((hipEvent_t)ev)); return TFHE_OK; }
+int tfhe_event_record(tfhe_ctx* c, void* ev) {
+    if (!c || !ev) return fail(TFHE_E_BADARG, "null argument");
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, c->stream));
+    return TFHE_OK;
+}
+int tfhe_event_elapsed_ms(void* a, void* b, float* ms) {
+    if (!a || !b || !ms) return fail(TFHE_E_BADARG, "null argument");
+    HIP_TRY(hipEventSynchronize((hipEvent_t)b));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return TFHE_OK;
+}
+
+}  // extern "C"
+
+#include "bfv_api.inc"
