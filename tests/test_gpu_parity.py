@@ -1,0 +1,404 @@
+"""GPU parity tests: the HIP engine, called through the C ABI (libtoyfhe_hip.so), against the oracle on
+the same seeded inputs -- bit-exact (integer work) -- plus the committed golden fixtures and
+size-independent properties at the BASELINE.json size (N = 2^14, L = 8)."""
+import os
+
+import numpy as np
+import pytest
+
+import toyfhe_jl_amd as tf
+from oracle import ref_cpu, spec
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+
+
+def dev(a):
+    return tf.DeviceBuffer.from_numpy(a)
+
+
+def run_ntt(ctx, a, inverse=False, idx=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    limbs = a.shape[-2]
+    count = a.size // (limbs * ctx.N)
+    d = dev(a)
+    (ctx.inntt if inverse else ctx.nntt)(d.ptr, d.ptr, count, limbs, idx)
+    return d.to_numpy(a.shape)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K1/K2
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("logn", [1, 2, 4, 5, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("bits,nq", [(40, 3), (50, 2), (61, 1)])
+def test_nntt_inntt_match_oracle(logn, bits, nq):
+    N = 1 << logn
+    qs = H.chain(bits, nq, N)
+    rng = np.random.default_rng(logn * 7 + bits)
+    a = H.rand_residues(rng, qs, (5,), N)
+    a[0, :, 0] = np.array(qs, dtype=np.uint64) - 1
+    ref = ref_cpu.RefCtx(N, qs)
+    ctx = tf.Context(N, qs)
+    assert ctx.psis == ref.psis
+    want = ref.nntt(a)
+    for variant in ((0, 1) if logn >= 10 else (0,)):
+        ctx.set_ntt_variant(variant)
+        got = run_ntt(ctx, a)
+        assert np.array_equal(got, want), (logn, bits, variant)
+        assert np.array_equal(run_ntt(ctx, want, inverse=True), a), (logn, bits, variant)
+
+
+@pytest.mark.parametrize("logn", [15, 16])
+def test_nntt_large_n(logn):
+    N = 1 << logn
+    qs = H.chain(50, 2, N)
+    rng = np.random.default_rng(logn)
+    a = H.rand_residues(rng, qs, (3,), N)
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    want = ref.nntt(a)
+    d_in, d_out = dev(a), tf.DeviceBuffer(a.size)
+    ctx.nntt(d_in.ptr, d_out.ptr, 3, 2)                # out of place
+    assert np.array_equal(d_out.to_numpy(a.shape), want)
+    assert np.array_equal(d_in.to_numpy(a.shape), a)   # source untouched
+    assert np.array_equal(run_ntt(ctx, a), want)       # in place
+    assert np.array_equal(run_ntt(ctx, want, inverse=True), a)
+
+
+def test_nntt_limb_selection_and_explicit_psi():
+    N = 2048
+    q, psi = 1152921504606830593, 811032584449645127    # cryptparams.jl:25
+    qs = H.chain(50, 3, N) + [q]
+    ref = ref_cpu.RefCtx(N, qs, [0, 0, 0, psi]); ctx = tf.Context(N, qs, [0, 0, 0, psi])
+    assert ctx.psis[3] == psi
+    rng = np.random.default_rng(3)
+    idx = [3, 1]
+    a = H.rand_residues(rng, [qs[i] for i in idx], (4,), N)
+    assert np.array_equal(run_ntt(ctx, a, idx=idx), ref.nntt(a, idx))
+    assert np.array_equal(run_ntt(ctx, G["pal_in"], idx=[3]), G["pal_ntt"])
+    with pytest.raises(AssertionError):
+        tf.Context(N, [q], [3])                          # psi^(2N) != 1 (pow2_cyc_rings.jl:31)
+    with pytest.raises(tf.UsageError):
+        run_ntt(ctx, a, idx=[0, 7])                      # limb outside the ring
+
+
+def test_golden_ntt_vectors():
+    for name, N in (("doc97", 4), ("n16", 16), ("n32", 32), ("n2048", 2048)):
+        ctx = tf.Context(N, G[f"{name}_q"], G[f"{name}_psi"])
+        x = G[f"{name}_in"]
+        x = x.reshape(-1, 1, N) if name == "doc97" else x
+        want = G[f"{name}_ntt"].reshape(x.shape)
+        assert np.array_equal(run_ntt(ctx, x), want), name
+        assert np.array_equal(run_ntt(ctx, want, inverse=True), x), name
+    # rlwe.md:207-212 products through the device
+    ctx = tf.Context(4, [97])
+    assert ctx.psis == [33]
+    nt = dev(G["doc97_ntt"])
+    for (i, j), want in zip([(2, 3), (0, 0), (0, 1)], G["doc97_prod"]):
+        o = tf.DeviceBuffer(4)
+        ctx.mul(nt.ptr + i * 32, nt.ptr + j * 32, o.ptr, 1, 1)
+        ctx.inntt(o.ptr, o.ptr, 1, 1)
+        assert np.array_equal(o.to_numpy(), want)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K3/K4/K5
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,bits,nq", [(16, 40, 2), (4096, 50, 3), (1024, 61, 2)])
+def test_limbwise_ops(N, bits, nq):
+    qs = H.chain(bits, nq, N)
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(N + bits)
+    a, b, c = (H.rand_residues(rng, qs, (3,), N) for _ in range(3))
+    a[0, :, :2] = 0; b[0, :, 0] = np.array(qs, dtype=np.uint64) - 1; a[1, :, 0] = np.array(qs, dtype=np.uint64) - 1
+    da, db, dc, do = dev(a), dev(b), dev(c), tf.DeviceBuffer(a.size)
+    for name in ("add", "sub", "mul"):
+        getattr(ctx, name)(da.ptr, db.ptr, do.ptr, 3, nq)
+        assert np.array_equal(do.to_numpy(a.shape), ref.pointwise(name, a, b)), name
+    ctx.neg(da.ptr, do.ptr, 3, nq)
+    assert np.array_equal(do.to_numpy(a.shape), ref.pointwise("neg", a))
+    ctx.mad(dc.ptr, da.ptr, db.ptr, do.ptr, 3, nq)
+    assert np.array_equal(do.to_numpy(a.shape), ref.pointwise("add", c, ref.pointwise("mul", a, b)))
+    s = 0x1234567890ABCDEF1234567890ABCDEF
+    ctx.scalar_mul([s % q for q in qs], da.ptr, do.ptr, 3, nq)
+    assert np.array_equal(do.to_numpy(a.shape), ref.scalar_mul([s % q for q in qs], a))
+    # tensor (rlwe_she.jl:255-258) in the NTT domain
+    x, y = H.rand_residues(rng, qs, (2, 2), N), H.rand_residues(rng, qs, (2, 2), N)
+    dx, dy, dt = dev(x), dev(y), tf.DeviceBuffer(2 * 3 * nq * N)
+    ctx.tensor(dx.ptr, dy.ptr, dt.ptr, 2, nq)
+    got = dt.to_numpy((2, 3, nq, N))
+    m = lambda u, v: ref.pointwise("mul", u, v)
+    assert np.array_equal(got[:, 0], m(x[:, 0], y[:, 0]))
+    assert np.array_equal(got[:, 1], ref.pointwise("add", m(x[:, 0], y[:, 1]), m(x[:, 1], y[:, 0])))
+    assert np.array_equal(got[:, 2], m(x[:, 1], y[:, 1]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# K6/K7/K8
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,bits,nq", [(32, 40, 3), (2048, 50, 4), (16384, 50, 3)])
+def test_rescale_select_galois(N, bits, nq):
+    qs = H.chain(bits, nq, N)
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(N)
+    a = H.rand_residues(rng, qs, (3,), N)
+    da = dev(a)
+    do = tf.DeviceBuffer(3 * (nq - 1) * N)
+    ctx.rescale(da.ptr, do.ptr, 3, nq)
+    assert np.array_equal(do.to_numpy((3, nq - 1, N)), ref.modswitch(a))
+    idx = [0, nq - 1]   # rescale by the last selected limb of a sub-basis
+    sub = np.ascontiguousarray(a[:, idx])
+    ds, d1 = dev(sub), tf.DeviceBuffer(3 * N)
+    ctx.rescale(ds.ptr, d1.ptr, 3, 2, idx)
+    assert np.array_equal(d1.to_numpy((3, 1, N)), ref.modswitch(sub, idx))
+    which = [nq - 1, 0]
+    dsel = tf.DeviceBuffer(3 * 2 * N)
+    ctx.select_limbs(da.ptr, dsel.ptr, 3, nq, which)
+    assert np.array_equal(dsel.to_numpy((3, 2, N)), a[:, which])
+    dg = tf.DeviceBuffer(a.size)
+    for g in (3, 5, 2 * N - 1, pow(3, N // 2 - 1, 2 * N), spec.galois_element_for_steps(1, N)):
+        ctx.galois(da.ptr, dg.ptr, g, 3, nq)
+        assert np.array_equal(dg.to_numpy(a.shape), ref.galois(g, a)), g
+    with pytest.raises(AssertionError):
+        ctx.galois(da.ptr, dg.ptr, 4, 3, nq)   # even element is not an automorphism
+
+
+def test_golden_modswitch_galois():
+    ctx = tf.Context(32, G["ms_q"])
+    da = dev(G["ms_in"]); do = tf.DeviceBuffer(3 * 2 * 32); dg = tf.DeviceBuffer(G["ms_in"].size)
+    ctx.rescale(da.ptr, do.ptr, 3, 3)
+    assert np.array_equal(do.to_numpy(G["ms_out"].shape), G["ms_out"])
+    for g in (3, 5, 63, pow(3, 15, 64)):
+        ctx.galois(da.ptr, dg.ptr, g, 3, 3)
+        assert np.array_equal(dg.to_numpy(G["ms_in"].shape), G[f"gal{g}_out"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# K9-K11: keyswitch / rotate
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,bits,Lk", [(32, 40, 4), (2048, 50, 3), (16384, 50, 4)])
+@pytest.mark.parametrize("special", [True, False])
+def test_keyswitch_matches_oracle(N, bits, Lk, special):
+    qs = H.chain(bits, Lk, N)
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(N + Lk)
+    evk = H.uniform_evk(rng, qs, Lk, N)
+    devk = dev(evk)
+    levels = (Lk - 1, 1) if special else (Lk, 2)
+    for level in levels:
+        for polys in (2, 3):
+            batch = 3
+            ct = H.rand_residues(rng, qs[:level], (batch, polys), N)
+            # centring edges of the RNS digits: 0, 1, q-1, floor(q/2), floor(q/2)+1
+            for l in range(level):
+                ct[0, polys - 1, l, :5] = [0, 1, qs[l] - 1, qs[l] // 2, qs[l] // 2 + 1]
+            dct, dout = dev(ct), tf.DeviceBuffer(batch * 2 * level * N)
+            ctx.keyswitch(Lk, level, special, devk.ptr, Lk, dct.ptr, polys, dout.ptr, batch)
+            want = ref.keyswitch(level, special, evk, ct)
+            assert np.array_equal(dout.to_numpy(want.shape), want), (level, polys)
+    with pytest.raises(AssertionError):
+        ctx.keyswitch(Lk, 1, special, devk.ptr, Lk, devk.ptr, 4, devk.ptr, 1)      # rlwe_she.jl:318
+    with pytest.raises(tf.UsageError):
+        ctx.keyswitch(Lk, Lk + 1, special, devk.ptr, Lk, devk.ptr, 2, devk.ptr, 1)  # level outside the key ring
+
+
+def test_golden_keyswitch_and_rotate():
+    ctx = tf.Context(32, G["ksS_q"])
+    devk, dct = dev(G["ksS_evk_ntt"]), dev(G["ksS_ct"])
+    dout = tf.DeviceBuffer(G["ksS_out"].size)
+    ctx.keyswitch(3, 2, True, devk.ptr, 3, dct.ptr, 2, dout.ptr, 2)
+    assert np.array_equal(dout.to_numpy(G["ksS_out"].shape), G["ksS_out"])
+    devk, dct = dev(G["ksR_evk_ntt"]), dev(G["ksR_ct"])
+    dout = tf.DeviceBuffer(G["ksR_out"].size)
+    ctx.keyswitch(3, 3, False, devk.ptr, 3, dct.ptr, 3, dout.ptr, 2)
+    assert np.array_equal(dout.to_numpy(G["ksR_out"].shape), G["ksR_out"])
+    # rotate = keyswitch ∘ apply_galois_element (rlwe_she.jl:359), against the oracle composition
+    ref = ref_cpu.RefCtx(32, G["ksS_q"])
+    g = spec.galois_element_for_steps(1, 32)
+    ct = G["ksS_ct"]
+    want = ref.keyswitch(2, True, G["ksS_evk_ntt"], ref.galois(g, ct.reshape(-1, 2, 32), [0, 1]).reshape(ct.shape))
+    devk, dct = dev(G["ksS_evk_ntt"]), dev(ct)
+    dout = tf.DeviceBuffer(want.size)
+    ctx.rotate(3, 2, True, devk.ptr, 3, g, dct.ptr, dout.ptr, 2)
+    assert np.array_equal(dout.to_numpy(want.shape), want)
+
+
+def test_keyswitch_decrypts_ckks_modraise():
+    """test/ckks_modraise.jl:10-30 end to end: encrypt (host), keyswitch s->s on the device, decrypt (host)."""
+    import random
+    N = 32
+    qs = spec.prime_chain(2**40 + 1, 3, N)
+    keyring = spec.Ring(N, qs); cring = keyring.drop_last()
+    prng = random.Random(77)
+    s, pub = spec.keygen(prng, keyring, 3.2)
+    ct = [spec.modswitch_drop_poly(c, keyring) for c in spec.encrypt_zero(prng, pub, keyring, 3.2)]
+    slots = np.arange(1, N // 2 + 1).astype(complex)
+    ct[0] = spec.poly_add(ct[0], spec.ckks_encode(slots, cring, 2**40), cring)
+    evk = spec.make_eval_key(prng, s, s, keyring, 3.2, premul=qs[-1])
+    evk_ntt = np.array([[spec.poly_nntt(m, keyring), spec.poly_nntt(md, keyring)] for m, md in evk], dtype=np.uint64)
+    ctx = tf.Context(N, qs)
+    dct, devk, dout = dev(np.array([ct], dtype=np.uint64)), dev(evk_ntt), tf.DeviceBuffer(2 * 2 * N)
+    ctx.keyswitch(3, 2, True, devk.ptr, 3, dct.ptr, 2, dout.ptr, 1)
+    out = dout.to_numpy((2, 2, N))
+    s_c = spec.modswitch_drop_poly(s, keyring)
+    dec = spec.ckks_decode(spec.decrypt_raw(s_c, [[list(map(int, l)) for l in p] for p in out], cring), cring, 2**40)
+    assert np.abs(dec - slots).max() < 1e-8          # the reference test's atol
+
+
+# ---------------------------------------------------------------------------------------------------
+# K12/K13: BFV
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["superset", "disjoint"])
+@pytest.mark.parametrize("N,bits,ns,nextra", [(32, 50, 3, 4), (2048, 50, 2, 3), (4096, 40, 2, 4), (1024, 60, 2, 3)])
+def test_bfv_expand_contract_mul(mode, N, bits, ns, nextra):
+    t = 65537
+    ch = H.chain(bits, 2 * ns + nextra + 1, N)
+    qs = ch[:ns]
+    pb = ch[: ns + nextra] if mode == "superset" else ch[ns: 2 * ns + nextra + 1]
+    rs, rb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, pb)
+    small, big = spec.Ring(N, qs), spec.Ring(N, pb)
+    if mode == "superset":
+        cbig = tf.Context(N, pb); csmall = cbig
+        plan = tf.BfvPlan(csmall, cbig, t, idx_s=list(range(ns)), idx_b=None)
+    else:
+        csmall, cbig = tf.Context(N, qs), tf.Context(N, pb)
+        plan = tf.BfvPlan(csmall, cbig, t)
+    rng = np.random.default_rng(N + ns)
+    a = H.rand_residues(rng, qs, (4,), N)
+    for k, x in enumerate([0, 1, small.Q - 1, small.Q // 2, small.Q // 2 + 1]):
+        a[0, :, k] = [x % q for q in qs]
+    da, de = dev(a), tf.DeviceBuffer(4 * len(pb) * N)
+    plan.expand(da.ptr, de.ptr, 4)
+    assert np.array_equal(de.to_numpy((4, len(pb), N)), ref_cpu.switch(rs, rb, a))
+    y = H.rand_residues(rng, pb, (3,), N)
+    tinv = pow(t, -1, big.Q)
+    edges = [0, 1, big.Q - 1, big.Q // 2, big.Q // 2 + 1, small.Q // 2, small.Q // 2 + 1, small.Q,
+             5 * small.Q + small.Q // 2, 5 * small.Q + small.Q // 2 + 1, big.Q - small.Q // 2 - 1]
+    for k, x in enumerate(edges):
+        y[0, :, k] = [(x * tinv) % big.Q % p for p in pb]
+    dy, dc = dev(y), tf.DeviceBuffer(3 * ns * N)
+    plan.contract(dy.ptr, dc.ptr, 3)
+    assert np.array_equal(dc.to_numpy((3, ns, N)), ref_cpu.contract(rb, rs, t, y))
+    batch = 5
+    plan.set_chunk(2)   # exercise the chunked pipeline incl. a ragged last chunk
+    c1, c2 = H.rand_residues(rng, qs, (batch, 2), N), H.rand_residues(rng, qs, (batch, 2), N)
+    d1, d2, do = dev(c1), dev(c2), tf.DeviceBuffer(batch * 3 * ns * N)
+    plan.mul(d1.ptr, d2.ptr, do.ptr, batch)
+    assert np.array_equal(do.to_numpy((batch, 3, ns, N)), ref_cpu.bfv_mul(rs, rb, t, c1, c2))
+
+
+def test_golden_bfv_vectors_and_decrypt():
+    q = G["bfvcrt_q"]                                   # test/bfv_crt.jl parameters, disjoint ℛbig
+    cs, cb = tf.Context(2048, q[:2]), tf.Context(2048, q[2:])
+    plan = tf.BfvPlan(cs, cb, int(G["bfvcrt_t"][0]))
+    ct = G["bfvcrt_ct"][None]
+    d, do = dev(ct), tf.DeviceBuffer(3 * 2 * 2048)
+    plan.mul(d.ptr, d.ptr, do.ptr, 1)
+    prod = do.to_numpy((3, 2, 2048))
+    assert np.array_equal(prod, G["bfvcrt_prod"])
+    small = spec.Ring(2048, [int(x) for x in q[:2]])
+    s = [[int(v) for v in l] for l in G["bfvcrt_secret"]]
+    dec = spec.bfv_decode(spec.decrypt_raw(s, [[[int(v) for v in l] for l in p] for p in prod], small), small, 53)
+    assert dec[0] == 36                                  # test/bfv_crt.jl:45-47
+    q = G["bfvsup_q"]
+    c = tf.Context(64, q)
+    plan = tf.BfvPlan(c, c, int(G["bfvsup_t"][0]), idx_s=[0, 1, 2])
+    d1, d2, do = dev(G["bfvsup_c1"][None]), dev(G["bfvsup_c2"][None]), tf.DeviceBuffer(3 * 3 * 64)
+    plan.mul(d1.ptr, d2.ptr, do.ptr, 1)
+    assert np.array_equal(do.to_numpy((3, 3, 64)), G["bfvsup_prod"])
+    with pytest.raises(NotImplementedError):
+        tf.BfvPlan(c, c, 65537, idx_s=[0, 1, 2], idx_b=[1, 2, 3, 4])   # partial overlap
+
+
+def test_bfv_mul_relin_matches_oracle_and_decrypts():
+    import random
+    N, t, ns = 1024, 65537, 3
+    ch = H.chain(50, 2 * ns + 2, N)
+    qs, pb = ch[:ns], ch
+    rs, rb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, pb)
+    ring = spec.Ring(N, qs)
+    secret, evk = H.real_evk(5, N, qs, special=False)
+    # genuine encryptions of 6 and 7 under `secret`
+    prng = random.Random(6); rng = np.random.default_rng(6)
+    s_l = [[int(v) for v in l] for l in secret]
+    def enc(m):
+        mask = [[prng.randrange(q) for _ in range(N)] for q in qs]
+        e = spec.poly_from_ints(spec.sample_gauss_ints(prng, N, 3.2), ring)
+        c0 = spec.poly_sub(spec.poly_add(spec.bfv_encode([m] + [0] * (N - 1), ring, t), e, ring), spec.poly_mul(mask, s_l, ring), ring)
+        return [c0, mask]
+    c1 = np.array([enc(6), enc(3)], dtype=np.uint64); c2 = np.array([enc(7), enc(5)], dtype=np.uint64)
+    ctx = tf.Context(N, pb)
+    plan = tf.BfvPlan(ctx, ctx, t, idx_s=list(range(ns)))
+    d1, d2, devk, do = dev(c1), dev(c2), dev(evk), tf.DeviceBuffer(2 * 2 * ns * N)
+    plan.mul_relin(devk.ptr, ns, d1.ptr, d2.ptr, do.ptr, 2)
+    got = do.to_numpy((2, 2, ns, N))
+    want = rs.keyswitch(ns, False, evk, ref_cpu.bfv_mul(rs, rb, t, c1, c2))
+    assert np.array_equal(got, want)
+    for b, m in enumerate((42, 15)):
+        dec = spec.bfv_decode(spec.decrypt_raw(s_l, [[[int(v) for v in l] for l in p] for p in got[b]], ring), ring, t)
+        assert dec[0] == m and not any(dec[1:])
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json size: N = 2^14, L = 8 (+9 extension limbs); properties + oracle on a sub-batch
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_bfv_mul_relin():
+    N, L, t = 1 << 14, 8, 65537
+    ch = H.chain(50, 17, N)
+    assert ch[:2] == [1125899908022273, 1125899908612097]     # BASELINE.md §3 moduli
+    qs = ch[:L]
+    ctx = tf.Context(N, ch)
+    plan = tf.BfvPlan(ctx, ctx, t, idx_s=list(range(L)))
+    rng = np.random.default_rng(2026)
+    batch = 24
+    c1, c2 = H.rand_residues(rng, qs, (batch, 2), N), H.rand_residues(rng, qs, (batch, 2), N)
+    evk = H.uniform_evk(rng, qs, L, N)
+    d1, d2, devk = dev(c1), dev(c2), dev(evk)
+    do = tf.DeviceBuffer(batch * 2 * L * N)
+    plan.set_chunk(16)
+    plan.mul_relin(devk.ptr, L, d1.ptr, d2.ptr, do.ptr, batch)
+    got = do.to_numpy((batch, 2, L, N))
+    # (1) oracle on a sub-batch (first, a middle one across the chunk boundary, last)
+    rs, rb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, ch)
+    pick = [0, 15, 16, batch - 1]
+    want = rs.keyswitch(L, False, evk, ref_cpu.bfv_mul(rs, rb, t, c1[pick], c2[pick]))
+    assert np.array_equal(got[pick], want)
+    # (2) commutativity of the ciphertext product: c1*c2 == c2*c1 bit for bit
+    do2 = tf.DeviceBuffer(batch * 2 * L * N)
+    plan.mul_relin(devk.ptr, L, d2.ptr, d1.ptr, do2.ptr, batch)
+    assert np.array_equal(do2.to_numpy(got.shape), got)
+    # (3) batch independence: a permuted batch gives the permuted result
+    perm = rng.permutation(batch)
+    d1p, d2p = dev(c1[perm]), dev(c2[perm])
+    plan.mul_relin(devk.ptr, L, d1p.ptr, d2p.ptr, do2.ptr, batch)
+    assert np.array_equal(do2.to_numpy(got.shape), got[perm])
+
+
+def test_full_size_ntt_properties():
+    N, L = 1 << 14, 8
+    qs = H.chain(50, L, N)
+    ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(99)
+    batch = 64
+    a, b = H.rand_residues(rng, qs, (batch,), N), H.rand_residues(rng, qs, (batch,), N)
+    da, db, ds, dn = dev(a), dev(b), tf.DeviceBuffer(a.size), tf.DeviceBuffer(a.size)
+    ctx.nntt(da.ptr, dn.ptr, batch, L)
+    fa = dn.to_numpy(a.shape)
+    ctx.inntt(dn.ptr, dn.ptr, batch, L)
+    assert np.array_equal(dn.to_numpy(a.shape), a)                       # round trip
+    ctx.add(da.ptr, db.ptr, ds.ptr, batch, L); ctx.nntt(ds.ptr, ds.ptr, batch, L)
+    ctx.nntt(db.ptr, db.ptr, batch, L)
+    ctx.add(dn.ptr, dn.ptr, dn.ptr, 0, L)                                # empty batch is a no-op
+    fb = db.to_numpy(a.shape)
+    ref = ref_cpu.RefCtx(N, qs)
+    assert np.array_equal(ds.to_numpy(a.shape), ref.pointwise("add", fa, fb))   # linearity
+    assert np.array_equal(fa[:2], ref.nntt(a[:2]))                       # oracle on a sub-batch
+    # â[k] = a(ψ^(2k+1)) spot check straight from the definition (pow2_cyc_rings.jl:278-294)
+    q, psi = qs[0], ctx.psis[0]
+    for k in (0, 1, N // 2, N - 1):
+        x = pow(psi, 2 * k + 1, q)
+        acc = 0
+        for c in reversed([int(v) for v in a[0, 0]]):
+            acc = (acc * x + c) % q
+        assert acc == int(fa[0, 0, k])

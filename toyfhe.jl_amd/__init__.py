@@ -1,0 +1,8 @@
+"""toyfhe.jl_amd -- MI355X-native engine for the power-of-two-cyclotomic RNS path of ToyFHE.jl.
+
+The directory name contains a dot, so import it through the repo-root loader module:
+``import toyfhe_jl_amd``.  Only what the hot path needs lives here: ``csrc/`` (HIP kernels + C ABI),
+``native`` (ctypes binding) and the host-side mirror of the reference's ring/ciphertext interface.
+"""
+from . import native  # noqa: F401
+from .native import BfvPlan, Context, DeviceBuffer, Event, HipError, UsageError  # noqa: F401

@@ -1,0 +1,328 @@
+"""ctypes binding of libtoyfhe_hip.so (include/toyfhe_hip.h).
+
+This is the only way the package computes anything: there is no CPU fallback.  If the HIP library
+is missing or no device is usable, every entry point raises -- loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libtoyfhe_hip.so")
+_SRC = os.path.join(_HERE, "csrc")
+_LIB = None
+
+u64p = C.POINTER(C.c_uint64)
+i32p = C.POINTER(C.c_int32)
+
+OK, E_BADARG, E_DOMAIN, E_LEVEL, E_PARAMS, E_NOMEM, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
+
+
+class UsageError(Exception):
+    """Mirror of ToyFHE.UsageError (src/rlwe_she.jl:223-225): operands with differing parameters."""
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/toyfhe_hip.hip for gfx950 into libtoyfhe_hip.so (in-tree)."""
+    srcs = [os.path.join(_SRC, f) for f in os.listdir(_SRC)] + [os.path.join(_HERE, "..", "include", "toyfhe_hip.h")]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
+        return _SO
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-shared", "-fPIC",
+           os.path.join(_SRC, "toyfhe_hip.hip"), "-o", _SO]
+    subprocess.check_call(cmd)
+    return _SO
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_SO):
+        raise HipError(f"{_SO} is missing: the HIP engine was not built "
+                       "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    L = C.CDLL(_SO)
+    L.tfhe_last_error.restype = C.c_char_p
+    vp, i64, i32, u64, sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_size_t
+    sig = {
+        "tfhe_device_count": [C.POINTER(C.c_int)],
+        "tfhe_set_device": [i32],
+        "tfhe_ctx_create": [i64, i32, u64p, u64p, C.POINTER(vp)],
+        "tfhe_ctx_destroy": [vp],
+        "tfhe_ctx_psi": [vp, u64p],
+        "tfhe_ctx_set_stream": [vp, vp],
+        "tfhe_ctx_sync": [vp],
+        "tfhe_ctx_set_ntt_variant": [vp, i32],
+        "tfhe_malloc": [sz, C.POINTER(vp)],
+        "tfhe_free": [vp],
+        "tfhe_memcpy_h2d": [vp, vp, sz],
+        "tfhe_memcpy_d2h": [vp, vp, sz],
+        "tfhe_memcpy_d2d": [vp, vp, vp, sz],
+        "tfhe_memset": [vp, vp, i32, sz],
+        "tfhe_nntt": [vp, vp, vp, i64, i32, i32p],
+        "tfhe_inntt": [vp, vp, vp, i64, i32, i32p],
+        "tfhe_add": [vp, vp, vp, vp, i64, i32, i32p],
+        "tfhe_sub": [vp, vp, vp, vp, i64, i32, i32p],
+        "tfhe_neg": [vp, vp, vp, i64, i32, i32p],
+        "tfhe_mul": [vp, vp, vp, vp, i64, i32, i32p],
+        "tfhe_mad": [vp, vp, vp, vp, vp, i64, i32, i32p],
+        "tfhe_scalar_mul": [vp, u64p, vp, vp, i64, i32, i32p],
+        "tfhe_tensor": [vp, vp, vp, vp, i64, i32, i32p],
+        "tfhe_rescale": [vp, vp, vp, i64, i32, i32p],
+        "tfhe_select_limbs": [vp, vp, vp, i64, i32, i32p, i32],
+        "tfhe_galois": [vp, vp, vp, u64, i64, i32, i32p],
+        "tfhe_keyswitch": [vp, i32, i32, i32, vp, i32, vp, i32, vp, i64],
+        "tfhe_rotate": [vp, i32, i32, i32, vp, i32, u64, vp, vp, i64],
+        "tfhe_bfv_plan_create": [vp, i32p, i32, vp, i32p, i32, u64, C.POINTER(vp)],
+        "tfhe_bfv_plan_destroy": [vp],
+        "tfhe_bfv_plan_set_chunk": [vp, i32],
+        "tfhe_bfv_mul": [vp, vp, vp, vp, i64],
+        "tfhe_bfv_expand": [vp, vp, vp, i64],
+        "tfhe_bfv_contract": [vp, vp, vp, i64],
+        "tfhe_bfv_mul_relin": [vp, vp, i32, vp, vp, vp, i64],
+        "tfhe_prof_enable": [vp, i32],
+        "tfhe_prof_read": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)],
+        "tfhe_event_create": [C.POINTER(vp)],
+        "tfhe_event_destroy": [vp],
+        "tfhe_event_record": [vp, vp],
+        "tfhe_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    _LIB = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "tfhe_last_error", "tfhe_device_count", "tfhe_set_device", "tfhe_ctx_create", "tfhe_ctx_destroy", "tfhe_ctx_psi",
+    "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
+    "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
+    "tfhe_mul", "tfhe_mad", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
+    "tfhe_keyswitch", "tfhe_rotate", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
+    "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
+    "tfhe_event_create", "tfhe_event_destroy", "tfhe_event_record", "tfhe_event_elapsed_ms",
+]
+
+
+def check(rc: int):
+    """Map a tfhe_status to the exception class the reference raises for the same condition."""
+    if rc == OK:
+        return
+    msg = lib().tfhe_last_error().decode("utf-8", "replace")
+    if rc == E_BADARG:
+        raise AssertionError(msg)            # @assert (pow2_cyc_rings.jl:31,61,116; rlwe_she.jl:318)
+    if rc in (E_PARAMS, E_LEVEL):
+        raise UsageError(msg)                # UsageError (rlwe_she.jl:223-225,233-235,248-250)
+    if rc == E_UNSUPPORTED:
+        raise NotImplementedError(msg)       # error("... only implemented ...") (crt.jl:270,274)
+    if rc == E_NOMEM:
+        raise MemoryError(msg)
+    raise HipError(msg)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().tfhe_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+def _idx(idx):
+    if idx is None:
+        return None
+    return (C.c_int32 * len(idx))(*[int(i) for i in idx])
+
+
+class DeviceBuffer:
+    """A flat device allocation of uint64 residues (owned by the library's allocator)."""
+
+    def __init__(self, n_words: int):
+        self.n = int(n_words)
+        p = C.c_void_p()
+        check(lib().tfhe_malloc(self.n * 8, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = cls(a.size)
+        check(lib().tfhe_memcpy_h2d(b.ptr, a.ctypes.data, a.size * 8))
+        return b
+
+    def to_numpy(self, shape=None) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.uint64)
+        check(lib().tfhe_memcpy_d2h(out.ctypes.data, self.ptr, self.n * 8))
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().tfhe_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """NegacyclicRing{CRTEncoded{L,...},N} on the device (tfhe_ctx)."""
+
+    def __init__(self, N: int, qs, psis=None):
+        self.N, self.qs = int(N), [int(q) for q in qs]
+        q = (C.c_uint64 * len(qs))(*self.qs)
+        ps = (C.c_uint64 * len(qs))(*([0] * len(qs) if psis is None else [int(p) for p in psis]))
+        h = C.c_void_p()
+        check(lib().tfhe_ctx_create(self.N, len(self.qs), q, ps, C.byref(h)))
+        self.h = h.value
+        out = (C.c_uint64 * len(qs))()
+        check(lib().tfhe_ctx_psi(self.h, out))
+        self.psis = [int(x) for x in out]
+
+    @property
+    def L(self):
+        return len(self.qs)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().tfhe_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib().tfhe_ctx_sync(self.h))
+
+    def set_stream(self, stream_ptr):
+        check(lib().tfhe_ctx_set_stream(self.h, stream_ptr))
+
+    def set_ntt_variant(self, v):
+        check(lib().tfhe_ctx_set_ntt_variant(self.h, int(v)))
+
+    # ---- raw ops on device pointers (ints) ----
+    def nntt(self, src, dst, count, limbs, idx=None):
+        check(lib().tfhe_nntt(self.h, src, dst, count, limbs, _idx(idx)))
+
+    def inntt(self, src, dst, count, limbs, idx=None):
+        check(lib().tfhe_inntt(self.h, src, dst, count, limbs, _idx(idx)))
+
+    def add(self, a, b, dst, count, limbs, idx=None):
+        check(lib().tfhe_add(self.h, a, b, dst, count, limbs, _idx(idx)))
+
+    def sub(self, a, b, dst, count, limbs, idx=None):
+        check(lib().tfhe_sub(self.h, a, b, dst, count, limbs, _idx(idx)))
+
+    def neg(self, a, dst, count, limbs, idx=None):
+        check(lib().tfhe_neg(self.h, a, dst, count, limbs, _idx(idx)))
+
+    def mul(self, a, b, dst, count, limbs, idx=None):
+        check(lib().tfhe_mul(self.h, a, b, dst, count, limbs, _idx(idx)))
+
+    def mad(self, acc, a, b, dst, count, limbs, idx=None):
+        check(lib().tfhe_mad(self.h, acc, a, b, dst, count, limbs, _idx(idx)))
+
+    def scalar_mul(self, scal, a, dst, count, limbs, idx=None):
+        s = (C.c_uint64 * limbs)(*[int(x) for x in scal])
+        check(lib().tfhe_scalar_mul(self.h, s, a, dst, count, limbs, _idx(idx)))
+
+    def tensor(self, a, b, out, batch, limbs, idx=None):
+        check(lib().tfhe_tensor(self.h, a, b, out, batch, limbs, _idx(idx)))
+
+    def rescale(self, src, dst, count, limbs, idx=None):
+        check(lib().tfhe_rescale(self.h, src, dst, count, limbs, _idx(idx)))
+
+    def select_limbs(self, src, dst, count, src_limbs, which):
+        check(lib().tfhe_select_limbs(self.h, src, dst, count, src_limbs, _idx(which), len(which)))
+
+    def galois(self, src, dst, g, count, limbs, idx=None):
+        check(lib().tfhe_galois(self.h, src, dst, int(g), count, limbs, _idx(idx)))
+
+    def keyswitch(self, key_limbs, level, special, evk, n_digits, ct, polys, out, batch):
+        check(lib().tfhe_keyswitch(self.h, key_limbs, level, int(bool(special)), evk, n_digits, ct, polys, out, batch))
+
+    def rotate(self, key_limbs, level, special, evk, n_digits, g, ct, out, batch):
+        check(lib().tfhe_rotate(self.h, key_limbs, level, int(bool(special)), evk, n_digits, int(g), ct, out, batch))
+
+    def prof_enable(self, on=True):
+        check(lib().tfhe_prof_enable(self.h, int(on)))
+
+    def prof_read(self):
+        a, b, ms = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        check(lib().tfhe_prof_read(self.h, C.byref(a), C.byref(b), C.byref(ms)))
+        return a.value, b.value, ms.value
+
+
+class BfvPlan:
+    """(ℛ, ℛbig, t) of a BFVParams (src/bfv.jl:5-19) with the exact-conversion tables on the device."""
+
+    def __init__(self, small: Context, big: Context, t: int, idx_s=None, idx_b=None):
+        self.small, self.big, self.t = small, big, int(t)
+        idx_s = list(range(small.L)) if idx_s is None else list(idx_s)
+        idx_b = list(range(big.L)) if idx_b is None else list(idx_b)
+        self.ns, self.nb = len(idx_s), len(idx_b)
+        h = C.c_void_p()
+        check(lib().tfhe_bfv_plan_create(small.h, _idx(idx_s), self.ns, big.h, _idx(idx_b), self.nb, self.t, C.byref(h)))
+        self.h = h.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().tfhe_bfv_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_chunk(self, n):
+        check(lib().tfhe_bfv_plan_set_chunk(self.h, int(n)))
+
+    def mul(self, c1, c2, out, batch):
+        check(lib().tfhe_bfv_mul(self.h, c1, c2, out, batch))
+
+    def expand(self, src, dst, count):
+        check(lib().tfhe_bfv_expand(self.h, src, dst, count))
+
+    def contract(self, src, dst, count):
+        check(lib().tfhe_bfv_contract(self.h, src, dst, count))
+
+    def mul_relin(self, evk, n_digits, c1, c2, out, batch):
+        check(lib().tfhe_bfv_mul_relin(self.h, evk, n_digits, c1, c2, out, batch))
+
+
+class Event:
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().tfhe_event_create(C.byref(p)))
+        self.p = p.value
+
+    def record(self, ctx: Context):
+        check(lib().tfhe_event_record(ctx.h, self.p))
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float(0)
+        check(lib().tfhe_event_elapsed_ms(self.p, stop.p, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.p:
+                lib().tfhe_event_destroy(self.p)
+        except Exception:
+            pass
