@@ -22,6 +22,18 @@ struct alignas(16) twd_t {  // twiddle (w, floor(w 2^64 / q)) -- one 16-byte loa
     u64 w, wp;
 };
 TFHE_HD tw_t as_tw(const twd_t& t) { return tw_t{t.w, t.wp}; }
+// Table pointers reach the kernels inside a struct loaded from memory, so the compiler only knows
+// them as generic pointers and would emit flat_load (which ties up the LDS counter as well).  They
+// always point to device global memory: say so.
+TFHE_HD tw_t ld_tw(const twd_t* tab, u32 i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(1))) const twd_t* gptr_t;
+    const gptr_t g = (gptr_t)tab;
+    return tw_t{g[i].w, g[i].wp};
+#else
+    return tw_t{tab[i].w, tab[i].wp};
+#endif
+}
 
 // Padded LDS layout (word = 8 bytes).  Chosen with tools/lds_conflict_sim.py: for LOGB=14,
 // 1024 threads, passes 4/4/4/2 every ds_read_b64/ds_write_b64 of every pass is conflict-free
@@ -87,7 +99,7 @@ TFHE_HD void ntt_fwd_pass(u64* lds, const u64* gsrc, u64* gdst, const twd_t* W, 
             const int half = 1 << (K - 1 - d);
 #pragma unroll
             for (int g = 0; g < (1 << d); g++) {
-                const tw_t w = as_tw(W[(pre << (S0 + d)) + (hi << d) + (u32)g]);
+                const tw_t w = ld_tw(W, (pre << (S0 + d)) + (hi << d) + (u32)g);
 #pragma unroll
                 for (int i = 0; i < half; i++) {
                     const int r0 = (g << (K - d)) + i;
@@ -147,7 +159,7 @@ TFHE_HD void ntt_inv_pass(u64* lds, const u64* gsrc, u64* gdst, const ntt_limb_t
                         v[r0 + half] = shoup_lazy(dd, L.w1inv_ninv, q);
                     }
                 } else {
-                    const tw_t w = as_tw(L.Winv[(pre << (S0 + d)) + (hi << d) + (u32)g]);
+                    const tw_t w = ld_tw(L.Winv, (pre << (S0 + d)) + (hi << d) + (u32)g);
 #pragma unroll
                     for (int i = 0; i < half; i++) {
                         const int r0 = (g << (K - d)) + i;
@@ -182,7 +194,7 @@ TFHE_HD void ntt_fwd_top(const u64* src, u64* dst, const twd_t* W, u64 q, u64 co
         const int half = 1 << (X - 1 - d);
 #pragma unroll
         for (int g = 0; g < (1 << d); g++) {
-            const tw_t w = as_tw(W[(1u << d) + (u32)g]);
+            const tw_t w = ld_tw(W, (1u << d) + (u32)g);
 #pragma unroll
             for (int i = 0; i < half; i++) bfly_fwd(v[(g << (X - d)) + i], v[(g << (X - d)) + i + half], w, q);
         }
@@ -211,7 +223,7 @@ TFHE_HD void ntt_inv_top(const u64* src, u64* dst, const ntt_limb_t& L, u64 col,
                     v[i + half] = shoup_lazy(dd, L.w1inv_ninv, q);
                 }
             } else {
-                const tw_t w = as_tw(L.Winv[(1u << d) + (u32)g]);
+                const tw_t w = ld_tw(L.Winv, (1u << d) + (u32)g);
 #pragma unroll
                 for (int i = 0; i < half; i++) bfly_inv(v[(g << (X - d)) + i], v[(g << (X - d)) + i + half], w, q);
             }
@@ -230,7 +242,7 @@ TFHE_HD void ntt_generic_fwd_stage(u64* lds, const twd_t* W, u64 q, int logn, in
     const u32 tbits = (u32)(logn - 1 - s);
     const u32 i = b >> tbits, jl = b & ((1u << tbits) - 1);
     const u32 j = (i << (tbits + 1)) + jl;
-    bfly_fwd(lds[j], lds[j + (1u << tbits)], as_tw(W[(1u << s) + i]), q);
+    bfly_fwd(lds[j], lds[j + (1u << tbits)], ld_tw(W, (1u << s) + i), q);
 }
 TFHE_HD void ntt_generic_inv_stage(u64* lds, const ntt_limb_t& L, int logn, int s, u32 b) {
     const u32 tbits = (u32)(logn - 1 - s);
@@ -242,6 +254,6 @@ TFHE_HD void ntt_generic_inv_stage(u64* lds, const ntt_limb_t& L, int logn, int 
         lds[j] = shoup_lazy(a, L.ninv, q);
         lds[j + (1u << tbits)] = shoup_lazy(d, L.w1inv_ninv, q);
     } else {
-        bfly_inv(lds[j], lds[j + (1u << tbits)], as_tw(L.Winv[(1u << s) + i]), L.q);
+        bfly_inv(lds[j], lds[j + (1u << tbits)], ld_tw(L.Winv, (1u << s) + i), L.q);
     }
 }
