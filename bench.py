@@ -38,15 +38,10 @@ def main():
 
     import toyfhe_jl_amd as tf
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+    from toyfhe_jl_amd import dist as tdist
+    world, rank, local_rank = tdist.env_world()
     torch.cuda.set_device(local_rank)
+    tdist.init(backend="nccl", device_id=torch.device("cuda", local_rank))
     tf.native.check(tf.native.lib().tfhe_set_device(local_rank))
     dev = torch.device("cuda", local_rank)
 
@@ -77,9 +72,7 @@ def main():
     def step():
         plan.mul_relin(evk.data_ptr(), L, c1.data_ptr(), c2.data_ptr(), out.data_ptr(), B)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = tdist.barrier
 
     for _ in range(args.warmup):
         step()
@@ -96,10 +89,7 @@ def main():
     launches, limb_polys, ntt_ms = ctx.prof_read()
     ctx.prof_enable(False)
     elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = tdist.max_over_ranks(elapsed, device=dev)
 
     total_units = B * world * args.steps
     value = total_units / elapsed
@@ -131,7 +121,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import ref_cpu
         cores = ref_cpu.lib().ref_num_threads()
-        ns = args.cpu_sample or max(cores, 8)
+        ns = args.cpu_sample or max(8 * cores, 8)
         rng = np.random.default_rng(1)
         s1, s2 = H.rand_residues(rng, qs, (ns, 2), N), H.rand_residues(rng, qs, (ns, 2), N)
         sk = H.uniform_evk(rng, qs, L, N)
@@ -146,7 +136,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
-        dist.destroy_process_group()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

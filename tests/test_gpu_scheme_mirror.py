@@ -1,0 +1,173 @@
+"""The host-side mirror of the reference interface (toyfhe.jl_amd/ring.py, she.py) driven the way the
+reference's own tests drive ToyFHE (test/*.jl): keygen -> encrypt -> homomorphic op -> decrypt.
+Every ring operation underneath runs on the MI355X through the C ABI."""
+import numpy as np
+import pytest
+
+import toyfhe_jl_amd as tf
+from oracle import ref_cpu, spec
+
+pytestmark = pytest.mark.gpu
+
+
+def chain(start, n, N):
+    out, p = [], tf.nextprime(start, 1, 2 * N)
+    for _ in range(n):
+        out.append(p)
+        p = tf.nextprime(p + 2 * N, 1, 2 * N)
+    return out
+
+
+def test_ring_element_semantics():
+    """docs/src/man/background/rlwe.md:186-212 through the mirror + lazy primal/dual rules."""
+    R = tf.NegacyclicRing(4, [97])
+    assert R.psi == [33] and R.degree() == 4 and R.modulus() == 97
+    p1, p2, p3, p4 = R([1, 1, 0, 0]), R([0, 0, 0, 1]), R([4, 0, 0, 0]), R([5, 0, 0, 0])
+    assert (p3 * p4).to_ints() == [20, 0, 0, 0]
+    assert (p1 ** 2).to_ints() == [1, 2, 1, 0]
+    assert (p1 * p2).to_ints() == [96, 0, 0, 1]
+    prod = p1 * p2
+    assert prod.primal is None and prod.dual is not None          # pow2_cyc_rings.jl:167: dual-only product
+    s = prod + p3                                                  # p3's dual is cached from p3*p4 -> dual only (:202-204)
+    assert s.primal is None and s.dual is not None
+    s = prod + R([4, 0, 0, 0])                                     # disjoint domains -> both computed (:205-216)
+    assert s.primal is not None and s.dual is not None and s.to_ints() == [3, 0, 0, 1]
+    s[1] = 5                                                       # setindex! invalidates the dual (:141-145)
+    assert s.dual is None and s[1] == 5
+    assert (-p1).to_ints() == [96, 96, 0, 0] and (p1 * 3).to_ints() == [3, 3, 0, 0] and (p1 - p1).to_ints() == [0] * 4
+    assert p1.apply_galois_element(3).to_ints() == [1, 0, 0, 1]   # x -> x^3
+    with pytest.raises(tf.UsageError):
+        p1 + tf.NegacyclicRing(4, [193])([1, 0, 0, 0])
+    with pytest.raises(AssertionError):
+        tf.NegacyclicRing(4, [97], [2])                            # pow2_cyc_rings.jl:31
+
+
+def test_rns_ring_constructor_and_crtselect():
+    R = tf.NegacyclicRing.from_logqs(32, (40, 40, 40))             # crt.jl:282-295
+    assert R.moduli == spec.rns_ring_primes(32, (40, 40, 40))
+    sub = R.crtselect([0, 2])
+    x = R([(-1) ** i * (i + 1) * 12345678901234567 for i in range(32)])
+    y = x.crtselect([0, 2])
+    assert y.ring == sub and np.array_equal(y.to_numpy(), x.to_numpy()[[0, 2]])
+    assert x.modswitch_drop().ring == R.drop_last()
+    ref = ref_cpu.RefCtx(32, R.moduli)
+    assert np.array_equal(x.modswitch().to_numpy(), ref.modswitch(x.to_numpy()[None])[0])
+
+
+def test_bfv_crt():
+    """test/bfv_crt.jl:8-47."""
+    n = 2048
+    ch = chain(2**50 + 1, 6, n)
+    R, Rbig = tf.NegacyclicRing(n, ch[:2]), tf.NegacyclicRing(n, ch[2:])
+    params = tf.BFVParams(R, Rbig, 53, 0, 3.2)
+    rng = np.random.default_rng(1)
+    kp = tf.keygen(rng, params)
+    plain = [6] + [0] * (n - 1)
+    c = tf.encrypt(rng, kp, plain)
+    assert tf.decrypt(kp, c)[0] == 6
+    y = c * c
+    assert len(y) == 3 and tf.decrypt(kp, y)[0] == 0x24
+    # relinearise with the RNS gadget and decrypt again
+    ek = tf.keygen_evalmult(rng, kp.priv)
+    z = tf.keyswitch(ek, y)
+    assert len(z) == 2 and tf.decrypt(kp, z)[0] == 36
+    assert tf.decrypt(kp, c + c)[0] == 12 and tf.decrypt(kp, c - c)[0] == 0
+    other = tf.BFVParams(R, Rbig, 53, 0, 3.2)
+    with pytest.raises(tf.UsageError):                              # rlwe_she.jl:248-250
+        c * tf.CipherText(other, c.cs)
+
+
+def test_bfv_superset_extension_basis_batch():
+    """the bench's basis relation (ℛbig ⊇ ℛ) on a batch of ciphertexts, slot-wise check of 6*7 etc."""
+    n, t = 1024, 65537
+    ch = chain(2**50 + 1, 7, n)
+    Rbig = tf.NegacyclicRing(n, ch)
+    R = Rbig.crtselect(range(3))
+    params = tf.BFVParams(R, Rbig, t)
+    rng = np.random.default_rng(2)
+    kp = tf.keygen(rng, params)
+    ms = [[m] + [0] * (n - 1) for m in (6, 3, 200)]
+    ws = [[w] + [0] * (n - 1) for w in (7, 5, 300)]
+    c1 = tf.encrypt(rng, kp, ms)
+    c2 = tf.encrypt(rng, kp, ws)
+    prod = tf.keyswitch(tf.keygen_evalmult(rng, kp.priv), c1 * c2)
+    dec = tf.decrypt(kp, prod)
+    assert [d[0] for d in dec] == [42, 15, 60000] and not any(any(d[1:]) for d in dec)
+
+
+def test_bgv_triv():
+    """test/bgv_triv.jl:6-21: PALISADE ring, single 60-bit modulus with explicit ψ, t = 256."""
+    R = tf.NegacyclicRing(2048, [1152921504606830593], [811032584449645127])   # cryptparams.jl:25
+    params = tf.BGVParams(R, 256)
+    rng = np.random.default_rng(3)
+    kp = tf.keygen(rng, params)
+    c = tf.encrypt(rng, kp, [6] + [0] * 2047)
+    assert tf.decrypt(kp, c)[0] == 6
+    y = c * c
+    assert tf.decrypt(kp, y)[0] == 0x24                            # 3-element decrypt b + s c2 + s^2 c3
+
+
+def _ckks_ring(N, n):
+    return tf.NegacyclicRing(N, chain(2**40 + 1, n, N))
+
+
+def test_ckks_modswitch():
+    """test/ckks_modswitch.jl:7-33."""
+    N = 32
+    R = _ckks_ring(N, 3)
+    scale = 2**60
+    plain = np.full(N // 2, 2.0, dtype=complex)
+    re = tf.ckks_encode(plain, R, scale)
+    ps = R.moduli[-1]
+    assert abs(tf.ckks_decode(re.modswitch(), scale / ps)[0] - 2.0) < 1e-5
+    params = tf.CKKSParams(R, 0, 3.2)
+    rng = np.random.default_rng(4)
+    kp = tf.keygen(rng, params)
+    c = tf.modswitch(tf.encrypt(rng, kp, re, scale=scale))
+    assert np.abs(tf.ckks_decode(tf.decrypt(kp, c), c.scale) - plain).max() < 1e-3
+
+
+def test_ckks_modraise_keyswitch_and_rotate():
+    """test/ckks_modraise.jl:10-30 (keyswitch s->s with the special prime, atol 1e-8) and the rotation of
+    test/ckks_rotate.jl:43-45 on the same ModulusRaised parameters (upstream's rotate test uses
+    relin_window=1 digit keys, which are host-only; the special-prime path is what infer.jl uses)."""
+    N = 32
+    R = _ckks_ring(N, 3)
+    params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    rng = np.random.default_rng(5)
+    kp = tf.keygen(rng, params)
+    scale = 2**40
+    plain = np.arange(1, N // 2 + 1).astype(complex)
+    plain[0] += 1j
+    c = tf.encrypt(rng, kp, tf.ckks_encode(plain, params.R_cipher(), scale), scale=scale)
+    assert c.ring() == R.drop_last()
+    ek = tf.make_eval_key(rng, kp.priv.secret, kp.priv)
+    assert len(ek.key) == 3                                         # L+1 gadget components
+    got = tf.ckks_decode(tf.decrypt(kp, tf.keyswitch(ek, c)), scale)
+    assert np.abs(got - plain).max() < 1e-8
+    gk = tf.keygen_galois(rng, kp.priv, steps=1)
+    got = tf.ckks_decode(tf.decrypt(kp, tf.rotate(gk, c)), scale)
+    assert np.abs(got - np.roll(plain, 1)).max() < 1e-7             # circshift(plain, 1)
+    re = tf.ckks_encode(plain, params.R_cipher(), scale)
+    assert np.abs(tf.ckks_decode(re.apply_galois_element(3), scale) - np.roll(plain, -1)).max() < 1e-9  # ckks_rotate.jl:25
+    with pytest.raises(AssertionError):
+        tf.keyswitch(ek, tf.CipherText(params, c.cs + c.cs))        # 4 components, rlwe_she.jl:318
+
+
+def test_ckks_mul_rescale_pipeline():
+    """the encrypted_mnist-style step: ct*ct -> relinearise (special prime) -> rescale."""
+    N = 64
+    R = _ckks_ring(N, 4)
+    params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    rng = np.random.default_rng(6)
+    kp = tf.keygen(rng, params)
+    scale = 2**40
+    a = np.linspace(0.5, 2.0, N // 2).astype(complex)
+    b = np.linspace(-1.0, 1.0, N // 2).astype(complex)
+    ca = tf.encrypt(rng, kp, tf.ckks_encode(a, params.R_cipher(), scale), scale=scale)
+    cb = tf.encrypt(rng, kp, tf.ckks_encode(b, params.R_cipher(), scale), scale=scale)
+    prod = tf.keyswitch(tf.keygen_evalmult(rng, kp.priv), ca * cb)
+    res = tf.modswitch(prod)
+    assert res.ring().L == 2 and abs(res.scale - scale * scale / R.moduli[2]) < 1
+    got = tf.ckks_decode(tf.decrypt(kp, res), res.scale)
+    assert np.abs(got - a * b).max() < 1e-5

@@ -6,3 +6,8 @@ The directory name contains a dot, so import it through the repo-root loader mod
 """
 from . import native  # noqa: F401
 from .native import BfvPlan, Context, DeviceBuffer, Event, HipError, UsageError  # noqa: F401
+from . import ring, she  # noqa: F401,E402
+from .ring import NegacyclicRing, RingElement, nextprime  # noqa: F401,E402
+from .she import (BFVParams, BGVParams, CKKSParams, CipherText, ModulusRaised, apply_galois_element,  # noqa: F401,E402
+                  ckks_decode, ckks_encode, decrypt, enc_mul, encrypt, keygen, keygen_evalmult, keygen_galois,
+                  keyswitch, make_eval_key, modswitch, rotate)

@@ -1,0 +1,529 @@
+"""Host-side mirror of ToyFHE's generic RLWE scheme and its BFV / BGV / CKKS / ModulusRaised parameter
+wrappers, over device-resident ``RingElement``s (see ring.py).
+
+Mirrors ``src/rlwe_she.jl`` (keys, CipherText, keygen/encrypt/decrypt, ``+ - *``, ``keyswitch``,
+``rotate``), ``src/bfv.jl`` (π, π⁻¹, mul_expand / mul_contract), ``src/bgv.jl``, ``src/ckks.jl`` +
+``src/ckksencoding.jl`` (encode / decode, ct ``modswitch``) and ``src/modulusraising.jl``.  The heavy
+operations -- ring products, ``enc_mul`` for BFV, ``keyswitch``, ``rotate``, ``modswitch`` -- run as
+single fused calls into libtoyfhe_hip.so; key generation, encryption and decryption are, as in the
+reference, thin host-side callers of ring arithmetic.
+
+Randomness cannot match Julia's (MersenneTwister + a forked Distributions); parity is defined on the
+deterministic operations given inputs.  Samplers take a ``numpy.random.Generator``.
+"""
+from __future__ import annotations
+
+import math
+from fractions import Fraction
+
+import numpy as np
+
+from . import native
+from .native import BfvPlan, DeviceBuffer, UsageError
+from .ring import NegacyclicRing, RingElement
+
+# --------------------------------------------------------------------------------------------------
+# samplers (poly.jl:7-23, crt.jl:146-148,277-279, bgv.jl:27-34)
+# --------------------------------------------------------------------------------------------------
+
+
+def sample_uniform(rng: np.random.Generator, ring: NegacyclicRing, batch=None) -> RingElement:
+    shape = (ring.N,) if batch is None else (batch, ring.N)
+    cols = [rng.integers(0, q, size=shape, dtype=np.uint64) for q in ring.moduli]
+    return RingElement.from_host(ring, np.stack(cols, axis=len(shape) - 1))
+
+
+def sample_normal_ints(rng: np.random.Generator, N: int, sigma: float, batch=None):
+    shape = (N,) if batch is None else (batch, N)
+    return np.rint(rng.normal(0.0, sigma, size=shape)).astype(np.int64)
+
+
+def lift_ints(ring: NegacyclicRing, ints: np.ndarray, scale: int = 1) -> RingElement:
+    """small signed integers -> RNS residues (CRTEncoded(x::Integer), crt.jl:91-95)"""
+    cols = [np.mod(ints.astype(object) * scale, q).astype(np.uint64) for q in ring.moduli]
+    return RingElement.from_host(ring, np.stack(cols, axis=ints.ndim - 1))
+
+
+# --------------------------------------------------------------------------------------------------
+# scheme parameters
+# --------------------------------------------------------------------------------------------------
+
+
+class SHESchemeParams:
+    relin_window = 0
+
+    def R_cipher(self) -> NegacyclicRing:
+        raise NotImplementedError
+
+    def R_key(self) -> NegacyclicRing:      # ℛ_key, rlwe_she.jl:26
+        return self.R_cipher()
+
+    def noise(self, rng, ring, batch=None):  # 𝒩
+        return lift_ints(ring, sample_normal_ints(rng, ring.N, self.sigma, batch))
+
+    def secret_dist(self, rng, ring, batch=None):  # 𝒢
+        return lift_ints(ring, sample_normal_ints(rng, ring.N, self.sigma, batch))
+
+    def mul_expand(self, c):                 # rlwe_she.jl:39
+        return None
+
+    def encode(self, plaintext):             # π⁻¹
+        raise NotImplementedError
+
+    def decode(self, b):                     # π
+        raise NotImplementedError
+
+
+class BFVParams(SHESchemeParams):
+    """BFVParams(ℛ, ℛbig, ℛplain, relin_window, σ, Δ), bfv.jl:5-19 (ℛplain given by its modulus t)."""
+
+    scheme_name = "BFV"
+
+    def __init__(self, ring: NegacyclicRing, ring_big: NegacyclicRing, t: int, relin_window: int = 0, sigma: float = 3.2):
+        self.ring, self.ring_big, self.t, self.relin_window, self.sigma = ring, ring_big, int(t), relin_window, sigma
+        self.delta = ring.modulus() // self.t            # test/bfv_crt.jl:35
+        self._plan = None
+
+    def R_cipher(self):
+        return self.ring
+
+    def plan(self) -> BfvPlan:
+        if self._plan is None:
+            self._plan = BfvPlan(self.ring.ctx, self.ring_big.ctx, self.t, self.ring.idx, self.ring_big.idx)
+        return self._plan
+
+    def encode(self, plain) -> RingElement:
+        """π⁻¹, bfv.jl:21-24: Δ * plaintext (a list of coefficients, or a list of such lists = a batch)."""
+        return self.ring(_map_plain(plain, lambda m: self.delta * (int(m) % self.t)))
+
+    def decode(self, b: RingElement):
+        """π, bfv.jl:26-29: mod(SignedMod(divround(x, Δ)), t)."""
+        Q = self.ring.modulus()
+
+        def one(x):
+            v = x - Q if x > Q // 2 else x
+            y = _div_ties_away(v, self.delta) % Q
+            y = y - Q if y > Q // 2 else y
+            return y % self.t
+        return _map_plain(b.to_ints(), one)
+
+
+class BGVParams(SHESchemeParams):
+    """BGVParams(ℛ, ℛplain, σ), bgv.jl:5-34 (no relin_window field: keyswitch is unsupported, as upstream)."""
+
+    scheme_name = "BGV"
+
+    def __init__(self, ring: NegacyclicRing, t: int, sigma: float = 8 / math.sqrt(2 * math.pi)):
+        self.ring, self.t, self.sigma = ring, int(t), sigma
+
+    def R_cipher(self):
+        return self.ring
+
+    def noise(self, rng, ring, batch=None):  # ShiftedDiscreteNormal, bgv.jl:27-34
+        return lift_ints(ring, sample_normal_ints(rng, ring.N, self.sigma, batch), self.t)
+
+    def encode(self, plain):
+        return self.ring(_map_plain(plain, lambda m: int(m) % self.t))
+
+    def decode(self, b):
+        Q = self.ring.modulus()
+        return _map_plain(b.to_ints(), lambda x: (x - Q if x > Q // 2 else x) % self.t)
+
+
+class CKKSParams(SHESchemeParams):
+    """CKKSParams(ℛ, relin_window, σ), ckks.jl:7-25."""
+
+    scheme_name = "CKKS"
+
+    def __init__(self, ring: NegacyclicRing, relin_window: int = 0, sigma: float = 8 / math.sqrt(2 * math.pi)):
+        self.ring, self.relin_window, self.sigma = ring, relin_window, sigma
+
+    def R_cipher(self):
+        return self.ring
+
+    def encode(self, plain):
+        return plain  # π⁻¹(params, plaintext) = ℛ(plaintext), ckks.jl:21
+
+    def decode(self, b):
+        return b      # π(params, b) = b, ckks.jl:22
+
+
+class ModulusRaised(SHESchemeParams):
+    """ModulusRaised{P}, modulusraising.jl:12-21: the last CRT prime is a special prime reserved for keys."""
+
+    def __init__(self, params: SHESchemeParams):
+        self.params = params
+        self.sigma = params.sigma
+        self.relin_window = params.relin_window
+        self.scheme_name = params.scheme_name + " (with special prime)"
+
+    def R_cipher(self):
+        return self.params.R_cipher().drop_last()
+
+    def R_key(self):
+        return self.params.R_key()
+
+    def noise(self, rng, ring, batch=None):
+        return self.params.noise(rng, ring, batch)
+
+    def secret_dist(self, rng, ring, batch=None):
+        return self.params.secret_dist(rng, ring, batch)
+
+    def encode(self, plain):
+        return self.params.encode(plain)
+
+    def decode(self, b):
+        return self.params.decode(b)
+
+
+def _map_plain(plain, f):
+    if len(plain) and hasattr(plain[0], "__len__"):
+        return [[f(m) for m in row] for row in plain]
+    return [f(m) for m in plain]
+
+
+def _div_ties_away(x: int, y: int) -> int:
+    """div(x, y, RoundNearestTiesAway), div_hacks.jl:120-135 (y > 0)."""
+    q, r = divmod(abs(x), y)
+    if 2 * r >= y:
+        q += 1
+    return q if x >= 0 else -q
+
+
+# --------------------------------------------------------------------------------------------------
+# keys and ciphertexts (rlwe_she.jl:67-149)
+# --------------------------------------------------------------------------------------------------
+
+
+class KeyComponent:
+    def __init__(self, mask: RingElement, masked: RingElement):
+        self.mask, self.masked = mask, masked
+
+
+class PrivKey:
+    def __init__(self, params, secret: RingElement):
+        self.params, self.secret = params, secret
+
+
+class PubKey:
+    def __init__(self, params, key: KeyComponent):
+        self.params, self.key = params, key
+
+
+class KeyPair:
+    def __init__(self, priv: PrivKey, pub: PubKey):
+        self.priv, self.pub = priv, pub
+
+
+class KeySwitchKey:
+    """KeySwitchKey{P}(params, key::Vector{KeyComponent}), rlwe_she.jl:87-91.  ``packed()`` is the device
+    layout the C ABI consumes: [n_digits][2 = mask, masked][Lk][N], NTT domain."""
+
+    def __init__(self, params, key):
+        self.params, self.key = params, list(key)
+        self._packed = None
+
+    def packed(self) -> DeviceBuffer:
+        if self._packed is None:
+            ring = self.key[0].mask.ring
+            sz = ring.L * ring.N
+            buf = DeviceBuffer(len(self.key) * 2 * sz)
+            for i, kc in enumerate(self.key):
+                for s, el in enumerate((kc.mask, kc.masked)):
+                    native.check(native.lib().tfhe_memcpy_d2d(ring.ctx.h, buf.ptr + ((i * 2 + s) * sz) * 8,
+                                                              el.coeffs_dual().ptr, sz * 8))
+            ring.ctx.sync()
+            self._packed = buf
+        return self._packed
+
+
+class EvalMultKey:
+    def __init__(self, key: KeySwitchKey):
+        self.key = key
+
+
+class GaloisKey:
+    def __init__(self, galois_element: int, key: KeySwitchKey):
+        self.galois_element, self.key = galois_element, key
+
+
+class CipherText:
+    """CipherText{Plain,P,T,N}(params, cs), rlwe_she.jl:131-149.  ``scale`` carries the CKKS FixedRational
+    denominator (a type parameter upstream, ckksencoding.jl:3-15)."""
+
+    def __init__(self, params, cs, scale=None):
+        self.params, self.cs, self.scale = params, tuple(cs), scale
+
+    def __len__(self):
+        return len(self.cs)
+
+    def __getitem__(self, i):
+        return self.cs[i]
+
+    def ring(self):
+        return self.cs[0].ring
+
+    def __repr__(self):
+        return f"{self.params.scheme_name} ciphertext (length {len(self.cs)})"
+
+    # homomorphic arithmetic, rlwe_she.jl:231-266
+    def _addsub(self, o, sub):
+        if self.params is not o.params:
+            raise UsageError("Attempting to add ciphertexts with differing parameters")
+        n = max(len(self), len(o))
+        cs = []
+        for i in range(n):
+            if i >= len(self):
+                cs.append(-o[i] if sub else o[i])
+            elif i >= len(o):
+                cs.append(self[i])
+            else:
+                cs.append(self[i] - o[i] if sub else self[i] + o[i])
+        return CipherText(self.params, cs, self.scale)
+
+    def __add__(self, o):
+        if isinstance(o, RingElement):  # +(c, b::T), rlwe_she.jl:243-245
+            return CipherText(self.params, (self.cs[0] + o,) + self.cs[1:], self.scale)
+        return self._addsub(o, False)
+
+    def __sub__(self, o):
+        return self._addsub(o, True)
+
+    def __mul__(self, o):
+        if isinstance(o, CipherText):
+            scale = None if self.scale is None else self.scale * o.scale  # ckksencoding.jl:133-135
+            return CipherText(self.params, enc_mul(self, o), scale)
+        if isinstance(o, int):
+            return CipherText(self.params, [c * o for c in self.cs], self.scale)
+        raise TypeError(type(o))
+
+
+# --------------------------------------------------------------------------------------------------
+# keygen / encrypt / decrypt (rlwe_she.jl:155-217, modulusraising.jl:23-26)
+# --------------------------------------------------------------------------------------------------
+
+
+def keygen(rng, params) -> KeyPair:
+    ring = params.R_key()
+    mask = sample_uniform(rng, ring)
+    secret = params.secret_dist(rng, ring)
+    error = params.noise(rng, ring)
+    masked = -(mask * secret + error)
+    return KeyPair(PrivKey(params, secret), PubKey(params, KeyComponent(mask, masked)))
+
+
+def encrypt_zero(rng, pub: PubKey, batch=None) -> CipherText:
+    params = pub.params
+    ring = params.R_key()
+    u = params.secret_dist(rng, ring, batch)
+    e1, e2 = params.noise(rng, ring, batch), params.noise(rng, ring, batch)
+    mask, masked = pub.key.mask, pub.key.masked
+    if batch is not None:  # broadcast the key over the batch
+        mask, masked = _broadcast(mask, batch), _broadcast(masked, batch)
+    c1 = masked * u + e1
+    c2 = mask * u + e2
+    cs = (c1, c2)
+    if isinstance(params, ModulusRaised):  # modulusraising.jl:23-26: drop the special limb
+        cs = tuple(c.modswitch_drop() for c in cs)
+    return CipherText(params, cs)
+
+
+def _broadcast(el: RingElement, batch: int) -> RingElement:
+    a = el.to_numpy("dual")
+    return RingElement.from_host(el.ring, np.broadcast_to(a, (batch,) + a.shape).copy(), dual=True)
+
+
+def encrypt(rng, key, plaintext, scale=None) -> CipherText:
+    pub = key.pub if isinstance(key, KeyPair) else key
+    enc = pub.params.encode(plaintext)
+    c = encrypt_zero(rng, pub, enc.batch)
+    c = c + enc  # rlwe_she.jl:190
+    c.scale = scale
+    return c
+
+
+def decrypt(key, c: CipherText):
+    priv = key.priv if isinstance(key, KeyPair) else key
+    secret = priv.secret
+    while secret.ring.L != c[0].ring.L:  # rlwe_she.jl:202-204
+        secret = secret.modswitch_drop()
+    if c[0].batch is not None:
+        secret = _broadcast(secret, c[0].batch)
+    b, spow = c[0], secret
+    for i in range(1, len(c)):
+        b = b + spow * c[i]
+        if i + 1 < len(c):
+            spow = spow * secret
+    return priv.params.decode(b)
+
+
+# --------------------------------------------------------------------------------------------------
+# multiplication (rlwe_she.jl:247-266 + bfv.jl:34-40)
+# --------------------------------------------------------------------------------------------------
+
+
+def enc_mul(c1: CipherText, c2: CipherText):
+    if c1.params is not c2.params:
+        raise UsageError("Attempting to multiply ciphertexts with differing parameters")
+    params = c1.params
+    ring, batch = c1[0].ring, c1[0].batch
+    n = c1[0].count
+    sz = ring.L * ring.N
+    if isinstance(params, BFVParams):
+        if len(c1) != 2 or len(c2) != 2:
+            raise NotImplementedError("BFV enc_mul on the device takes 2-element ciphertexts")
+        a, b = _pack([c.coeffs_primal() for c in c1.cs], ring, n), _pack([c.coeffs_primal() for c in c2.cs], ring, n)
+        out = DeviceBuffer(n * 3 * sz)
+        params.plan().mul(a.ptr, b.ptr, out.ptr, n)
+        return _unpack(out, ring, n, 3, batch, primal=True)
+    if len(c1) == 2 and len(c2) == 2:  # mul_expand / mul_contract are the identity (rlwe_she.jl:39-40)
+        a, b = _pack([c.coeffs_dual() for c in c1.cs], ring, n), _pack([c.coeffs_dual() for c in c2.cs], ring, n)
+        out = DeviceBuffer(n * 3 * sz)
+        ring.ctx.tensor(a.ptr, b.ptr, out.ptr, n, ring.L, ring.idx)
+        return _unpack(out, ring, n, 3, batch, primal=False)
+    cs = [None] * (len(c1) + len(c2) - 1)  # generic convolution of components
+    for i in range(len(c1)):
+        for j in range(len(c2)):
+            p = c1[i] * c2[j]
+            cs[i + j] = p if cs[i + j] is None else cs[i + j] + p
+    return tuple(cs)
+
+
+def _pack(bufs, ring, n) -> DeviceBuffer:
+    """[poly](n, L, N) -> (n, polys, L, N)"""
+    P, sz = len(bufs), ring.L * ring.N
+    out = DeviceBuffer(n * P * sz)
+    lib = native.lib()
+    for p, b in enumerate(bufs):
+        for k in range(n):
+            native.check(lib.tfhe_memcpy_d2d(ring.ctx.h, out.ptr + ((k * P + p) * sz) * 8, b.ptr + (k * sz) * 8, sz * 8))
+    return out
+
+
+def _unpack(buf, ring, n, P, batch, primal=True):
+    sz = ring.L * ring.N
+    lib = native.lib()
+    outs = []
+    for p in range(P):
+        o = DeviceBuffer(n * sz)
+        for k in range(n):
+            native.check(lib.tfhe_memcpy_d2d(ring.ctx.h, o.ptr + (k * sz) * 8, buf.ptr + ((k * P + p) * sz) * 8, sz * 8))
+        outs.append(RingElement(ring, o, None, batch) if primal else RingElement(ring, None, o, batch))
+    ring.ctx.sync()  # `buf` may be released by the caller as soon as we return
+    return tuple(outs)
+
+
+# --------------------------------------------------------------------------------------------------
+# key switching (rlwe_she.jl:273-360, modulusraising.jl:28-49)
+# --------------------------------------------------------------------------------------------------
+
+
+def make_eval_key(rng, old: RingElement, new: PrivKey) -> KeySwitchKey:
+    """make_eval_key(rng, old => new), rlwe_she.jl:273-298 with the RNS gadget (:287); ModulusRaised
+    pre-multiplies ``old`` by the special prime (modulusraising.jl:28-32)."""
+    params = new.params
+    if params.relin_window != 0:
+        raise NotImplementedError("digit-window (relin_window != 0) evaluation keys are host-only upstream "
+                                  "(rlwe_she.jl:281-283); the device path implements the RNS gadget")
+    ring = old.ring
+    if isinstance(params, ModulusRaised):
+        old = old * ring.moduli[-1]
+    res = old.to_numpy("primal")
+    key = []
+    for i in range(ring.L):
+        g = np.zeros_like(res)
+        g[i] = res[i]                                     # CRTResidual, crt.jl:64-77
+        mask = sample_uniform(rng, ring)
+        e = params.noise(rng, ring)
+        masked = RingElement.from_host(ring, g) - (mask * new.secret + e)
+        key.append(KeyComponent(mask, masked))
+    return KeySwitchKey(params, key)
+
+
+def keygen_evalmult(rng, priv: PrivKey) -> EvalMultKey:
+    return EvalMultKey(make_eval_key(rng, priv.secret * priv.secret, priv))  # rlwe_she.jl:299
+
+
+def galois_element_for_steps(steps: int, N: int) -> int:
+    return pow(3, 2 * N - steps, 2 * N) if steps > 0 else pow(3, -steps, 2 * N)  # rlwe_she.jl:304
+
+
+def keygen_galois(rng, priv: PrivKey, galois_element=None, steps=None) -> GaloisKey:
+    assert (galois_element is None) != (steps is None)  # rlwe_she.jl:301
+    if galois_element is None:
+        galois_element = galois_element_for_steps(steps, priv.secret.ring.N)
+    return GaloisKey(galois_element, make_eval_key(rng, priv.secret.apply_galois_element(galois_element), priv))
+
+
+def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
+    """keyswitch(ek, c), rlwe_she.jl:315-349 -- one fused device call."""
+    if isinstance(ek, (EvalMultKey, GaloisKey)):
+        ek = ek.key
+    if len(c) not in (2, 3):
+        raise AssertionError("keyswitch needs a 2- or 3-element ciphertext")  # rlwe_she.jl:318
+    params = ek.params
+    if params.relin_window != 0:
+        raise NotImplementedError("digit-window keyswitch (relin_window != 0) is not on the device path")
+    keyring = ek.key[0].mask.ring
+    special = isinstance(params, ModulusRaised)
+    ring, n, batch = c[0].ring, c[0].count, c[0].batch
+    level = ring.L
+    if keyring.idx != list(range(keyring.L)) or ring.idx != list(range(level)):
+        raise UsageError("ciphertext ring is not a prefix of the key ring")
+    sz = level * ring.N
+    ct = _pack([x.coeffs_primal() for x in c.cs], ring, n)
+    out = DeviceBuffer(n * 2 * sz)
+    if _galois is None:
+        keyring.ctx.keyswitch(keyring.L, level, special, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n)
+    else:
+        keyring.ctx.rotate(keyring.L, level, special, ek.packed().ptr, len(ek.key), _galois, ct.ptr, out.ptr, n)
+    return CipherText(c.params, _unpack(out, ring, n, 2, batch, primal=True), c.scale)
+
+
+def apply_galois_element(c: CipherText, g: int) -> CipherText:
+    return CipherText(c.params, [x.apply_galois_element(g) for x in c.cs], c.scale)  # rlwe_she.jl:355-357
+
+
+def rotate(gk: GaloisKey, c: CipherText) -> CipherText:
+    """rotate(gk, c) = keyswitch(gk, apply_galois_element(c, g)), rlwe_she.jl:359 (fused on the device)."""
+    if len(c) != 2:
+        raise AssertionError("rotate takes a 2-element ciphertext")
+    return keyswitch(gk.key, c, _galois=gk.galois_element)
+
+
+def modswitch(c: CipherText) -> CipherText:
+    """modswitch(::CipherText{CKKSEncoding}), ckksencoding.jl:127-130: rescale every component by the
+    last modulus; the scale is divided by it."""
+    q_last = c[0].ring.moduli[-1]
+    scale = None if c.scale is None else c.scale / q_last
+    return CipherText(c.params, [x.modswitch() for x in c.cs], scale)
+
+
+# --------------------------------------------------------------------------------------------------
+# CKKS encoding (float; ckksencoding.jl:43-97, ckks.jl:35-59) -- host side, tolerance-level parity
+# --------------------------------------------------------------------------------------------------
+
+
+def ckks_encode(slots, ring: NegacyclicRing, scale) -> RingElement:
+    n2 = len(slots)
+    N, M = 2 * n2, 4 * n2
+    assert N == ring.N
+    cm = np.zeros(N, dtype=np.complex128)
+    for i in range(n2):
+        e = pow(3, i + 1, M)
+        cm[e >> 1] = slots[i]
+        cm[((M - e) % M) >> 1] = np.conj(slots[i])
+    ip = np.fft.ifft(cm)
+    tw = np.exp(1j * (np.arange(N) * 2 / (2 * N)) * np.pi)
+    real = (ip * tw).real
+    ints = [int(round(Fraction(float(x)) * Fraction(scale))) for x in real]  # round(BigInt, big(x)*denom), ckks.jl:42
+    return ring(ints)
+
+
+def ckks_decode(el: RingElement, scale) -> np.ndarray:
+    ring = el.ring
+    N, Q = ring.N, ring.modulus()
+    vals = np.array([float(Fraction(x - Q if x > Q // 2 else x) / Fraction(scale)) for x in el.to_ints()])
+    tw = np.exp(-1j * (np.arange(N) * 2 / (2 * N)) * np.pi)
+    f = np.fft.fft(vals * tw)
+    return f[[pow(3, c, 2 * N) >> 1 for c in range(1, N // 2 + 1)]]
