@@ -57,8 +57,9 @@ int tfhe_ctx_destroy(tfhe_ctx *ctx);
 int tfhe_ctx_psi(const tfhe_ctx *ctx, uint64_t *psi_out /* [L] */);
 int tfhe_ctx_set_stream(tfhe_ctx *ctx, void *hip_stream /* hipStream_t, NULL = library-owned */);
 int tfhe_ctx_sync(tfhe_ctx *ctx);
-/* choose the NTT kernel family: 0 = auto (register-blocked LDS kernel when available),
- * 1 = force the generic radix-2 kernel (cross-check path used by the tests) */
+/* choose the NTT kernel family: 0 = auto (register-blocked LDS kernel; exact-integer fp64 butterflies
+ * when every selected modulus is < 1.125*2^50, u64 Shoup butterflies otherwise), 1 = force the generic
+ * radix-2 kernel, 2 = force the u64 register-blocked kernel (1 and 2 are cross-check paths for tests) */
 int tfhe_ctx_set_ntt_variant(tfhe_ctx *ctx, int variant);
 
 /* ---- device memory helpers (for callers without a GPU array package) ------------------------- */

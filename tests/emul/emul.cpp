@@ -17,39 +17,49 @@ static long g_slow_hits = 0;
 
 namespace {
 
-constexpr int pass_k_fwd(int logb, int s0) { return (logb - s0) >= 4 ? 4 : (logb - s0); }
-constexpr int pass_k_inv(int s_end) { return (s_end % 4) ? (s_end % 4) : 4; }
 
-template <int LOGB, int LOGT, int S0>
-void fwd_sched(u64* lds, const u64* gsrc, u64* gdst, const twd_t* W, u64 q, u32 pre, int x, u32 sbrev) {
-    constexpr int K = pass_k_fwd(LOGB, S0);
+template <class A, int LOGB, int LOGT, int S0>
+void fwd_sched(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 pre, int x, u32 sbrev) {
+    constexpr int K = pass_k_fwd(LOGB, LOGT, S0);
     constexpr bool LAST = (S0 + K == LOGB);
     for (u32 tid = 0; tid < (1u << LOGT); tid++)
-        ntt_fwd_pass<LOGB, LOGT, S0, K, S0 == 0, LAST>(lds, gsrc, gdst, W, q, tid, pre, x, sbrev);
-    if constexpr (!LAST) fwd_sched<LOGB, LOGT, S0 + K>(lds, gsrc, gdst, W, q, pre, x, sbrev);
+        ntt_fwd_pass<A, LOGB, LOGT, S0, K, S0 == 0, LAST>(lds, gsrc, gdst, C, tid, pre, x, sbrev);
+    if constexpr (!LAST) fwd_sched<A, LOGB, LOGT, S0 + K>(lds, gsrc, gdst, C, pre, x, sbrev);
 }
-template <int LOGB, int LOGT, int SEND, bool SCALE>
-void inv_sched(u64* lds, const u64* gsrc, u64* gdst, const ntt_limb_t& L, u32 pre, int x, u32 sbrev) {
-    constexpr int K = pass_k_inv(SEND);
+template <class A, int LOGB, int LOGT, int SEND, bool SCALE>
+void inv_sched(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 pre, int x, u32 sbrev) {
+    constexpr int K = pass_k_inv(LOGB, LOGT, SEND);
     constexpr int S0 = SEND - K;
     for (u32 tid = 0; tid < (1u << LOGT); tid++)
-        ntt_inv_pass<LOGB, LOGT, S0, K, SEND == LOGB, S0 == 0, SCALE>(lds, gsrc, gdst, L, tid, pre, x, sbrev);
-    if constexpr (S0 != 0) inv_sched<LOGB, LOGT, S0, SCALE>(lds, gsrc, gdst, L, pre, x, sbrev);
+        ntt_inv_pass<A, LOGB, LOGT, S0, K, SEND == LOGB, S0 == 0, SCALE>(lds, gsrc, gdst, C, tid, pre, x, sbrev);
+    if constexpr (S0 != 0) inv_sched<A, LOGB, LOGT, S0, SCALE>(lds, gsrc, gdst, C, pre, x, sbrev);
 }
 
+template <class A, int LOGB>
+void block_fwd_a(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
+    std::vector<u64> lds(lds_words<LOGB, logt_for(LOGB)>());
+    const typename A::ctx C = A::make(L);
+    for (u32 sb = 0; sb < (1u << x); sb++)
+        fwd_sched<A, LOGB, logt_for(LOGB), 0>(lds.data(), src + ((size_t)sb << LOGB), dst, C, (1u << x) + sb, x, brev_bits(sb, x));
+}
+template <class A, int LOGB>
+void block_inv_a(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
+    std::vector<u64> lds(lds_words<LOGB, logt_for(LOGB)>());
+    const typename A::ctx C = A::make(L);
+    for (u32 sb = 0; sb < (1u << x); sb++) {
+        if (x == 0) inv_sched<A, LOGB, logt_for(LOGB), LOGB, true>(lds.data(), src, dst, C, 1u, 0, 0u);
+        else inv_sched<A, LOGB, logt_for(LOGB), LOGB, false>(lds.data(), src, dst + ((size_t)sb << LOGB), C, (1u << x) + sb, x, brev_bits(sb, x));
+    }
+}
+// fp64 butterflies when the modulus qualifies and the caller did not force the u64 path (mirrors sel_fp in toyfhe_hip.hip)
+static bool g_force_int = false;
 template <int LOGB>
 void block_fwd(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
-    std::vector<u64> lds(lds_words(LOGB));
-    for (u32 sb = 0; sb < (1u << x); sb++)
-        fwd_sched<LOGB, LOGB - 4, 0>(lds.data(), src + ((size_t)sb << LOGB), dst, L.W, L.q, (1u << x) + sb, x, brev_bits(sb, x));
+    if (L.Wd && x == 0 && !g_force_int) block_fwd_a<ArithFp, LOGB>(src, dst, L, x); else block_fwd_a<ArithInt, LOGB>(src, dst, L, x);
 }
 template <int LOGB>
 void block_inv(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
-    std::vector<u64> lds(lds_words(LOGB));
-    for (u32 sb = 0; sb < (1u << x); sb++) {
-        if (x == 0) inv_sched<LOGB, LOGB - 4, LOGB, true>(lds.data(), src, dst, L, 1u, 0, 0u);
-        else inv_sched<LOGB, LOGB - 4, LOGB, false>(lds.data(), src, dst + ((size_t)sb << LOGB), L, (1u << x) + sb, x, brev_bits(sb, x));
-    }
+    if (L.Wd && x == 0 && !g_force_int) block_inv_a<ArithFp, LOGB>(src, dst, L, x); else block_inv_a<ArithInt, LOGB>(src, dst, L, x);
 }
 
 template <int X>
@@ -67,14 +77,17 @@ void top_inv(const u64* src, u64* dst, const ntt_limb_t& L, int logn) {
 
 extern "C" {
 
-// one limb-polynomial transform; variant 0 = register-blocked path (logn >= 10), 1 = generic radix-2.
+// one limb-polynomial transform; variant 0 = register-blocked path (logn >= 10; fp64 butterflies when the
+// modulus qualifies), 1 = generic radix-2, 2 = register-blocked path with u64 butterflies forced.
 // returns 0, -1 on bad psi, -2 on unsupported size
 int emul_ntt(int logn, uint64_t q, uint64_t psi, int inverse, int variant, const uint64_t* src, uint64_t* dst) {
     const int64_t N = 1ll << logn;
     if (!psi) psi = hostmath::minimal_primitive_root(q, 2 * (u64)N);
     std::vector<twd_t> W, Wi;
+    std::vector<ftwd_t> Wd, Wid;
     ntt_limb_t L;
-    if (build_ntt_tables(N, q, psi, W, Wi, &L)) return -1;
+    if (build_ntt_tables(N, q, psi, W, Wi, &L, &Wd, &Wid)) return -1;
+    g_force_int = (variant == 2);
     if (variant == 1 || logn < 10) {
         if (logn > 14) return -2;
         std::vector<u64> lds((size_t)N);

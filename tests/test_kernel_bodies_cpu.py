@@ -25,11 +25,35 @@ def test_ntt_bodies_match_oracle(logn, bits):
     a = rng.integers(0, q, size=N, dtype=np.uint64)
     a[0] = q - 1; a[-1] = 0   # range edges
     want = ctx.nntt(a.reshape(1, 1, N)).reshape(N)
-    for variant in ((0, 1) if logn >= 10 else (1,)):
+    # variant 0: register-blocked (fp64 butterflies for the 30- and 50-bit primes, u64 for the 61-bit one),
+    # 1: generic radix-2, 2: register-blocked with u64 butterflies forced
+    for variant in ((0, 1, 2) if logn >= 10 else (1,)):
         got = emul.ntt(a, q, variant=variant)
         assert np.array_equal(got, want), (logn, bits, variant)
         back = emul.ntt(want, q, inverse=True, variant=variant)
         assert np.array_equal(back, a), (logn, bits, variant)
+
+
+@pytest.mark.parametrize("logn", [10, 12, 14])
+def test_fp64_butterflies_at_the_modulus_limit_and_worst_case_inputs(logn):
+    """fp64arith.h is valid for q < 1.125*2^50: take the largest NTT-friendly prime below that bound and
+    inputs that maximise growth (all q-1, alternating 0 / q-1, all (q-1)/2)."""
+    N = 1 << logn
+    q = (1266637395197952 // (2 * N)) * (2 * N) + 1
+    while q >= 1266637395197952 or not spec.is_prime(q):
+        q -= 2 * N
+    assert q > 1.124 * 2**50
+    ctx = ref_cpu.RefCtx(N, [q])
+    pats = [np.full(N, q - 1, dtype=np.uint64), np.array([0, q - 1] * (N // 2), dtype=np.uint64),
+            np.full(N, (q - 1) // 2, dtype=np.uint64), np.random.default_rng(logn).integers(0, q, size=N, dtype=np.uint64)]
+    for a in pats:
+        want = ctx.nntt(a.reshape(1, 1, N)).reshape(N)
+        assert np.array_equal(emul.ntt(a, q, variant=0), want)
+        assert np.array_equal(emul.ntt(a, q, variant=2), want)
+        assert np.array_equal(emul.ntt(want, q, inverse=True, variant=0), a)
+        # inverse on growth-maximising NTT-domain inputs as well
+        wi = ctx.inntt(a.reshape(1, 1, N)).reshape(N)
+        assert np.array_equal(emul.ntt(a, q, inverse=True, variant=0), wi)
 
 
 @pytest.mark.parametrize("logn", [15, 16])

@@ -1,0 +1,59 @@
+// tools/ntt_ablate.hip -- standalone timing / ablation harness for the N = 2^14 NTT kernels (design aid).
+// Build (from repo root): hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value [-DABL=n] \
+//                         tools/ntt_ablate.hip -o tools/bin/ntt_ablate[_n]
+// ABL: 0 full kernel; see ntt_core.h hooks (TFHE_ABL_*) for what each variant removes.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "../toyfhe.jl_amd/csrc/kernels.h"
+#include "../toyfhe.jl_amd/csrc/ntt_tables.h"
+
+template <class A>
+void run(const char* name, const ntt_limb_t* LT, int L, u64* d_a, u64* d_b, int rows, bool inverse) {
+    limb_sel_t sel; sel.n = L; for (int j = 0; j < L; j++) sel.idx[j] = j;
+    const size_t lds = (size_t)lds_words<14, logt_for(14)>() * 8;
+    auto kf = k_ntt_fwd_block<A, 14, logt_for(14)>; auto ki = k_ntt_inv_block<A, 14, logt_for(14)>;
+    hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int grid = rows < 256 ? rows : 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(e0);
+        for (int it = 0; it < 5; it++) {
+            if (inverse) hipLaunchKernelGGL(ki, dim3(grid), dim3(1 << logt_for(14)), lds, 0, d_a, d_b, LT, sel, 0, (u32)rows);
+            else hipLaunchKernelGGL(kf, dim3(grid), dim3(1 << logt_for(14)), lds, 0, d_a, d_b, LT, sel, 0, (u32)rows);
+        }
+        hipEventRecord(e1); hipEventSynchronize(e1);
+    }
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    const double gbs = (double)rows * 2 * 16384 * 8 / (ms * 1e-3) / 1e9;
+    printf("%-28s rows=%d  %.3f ms  %.0f GB/s  (%.2f us per workgroup-slot)\n", name, rows, ms, gbs, ms * 1e3 / (rows / 256.0));
+}
+
+int main(int argc, char** argv) {
+    const int64_t N = 16384; const int L = 8;
+    int rows = argc > 1 ? atoi(argv[1]) : 4096;
+    std::vector<ntt_limb_t> LT(L);
+    u64 q = (1ull << 50) + 1;
+    for (int l = 0; l < L; l++) {
+        do { q += 2 * N; } while (!hostmath::is_prime(q));
+        std::vector<twd_t> W, Wi; std::vector<ftwd_t> Wd, Wid;
+        build_ntt_tables(N, q, hostmath::minimal_primitive_root(q, 2 * N), W, Wi, &LT[l], &Wd, &Wid);
+        twd_t *a, *b; ftwd_t *c, *d;
+        hipMalloc(&a, N * 16); hipMalloc(&b, N * 16); hipMalloc(&c, N * 16); hipMalloc(&d, N * 16);
+        hipMemcpy(a, W.data(), N * 16, hipMemcpyHostToDevice); hipMemcpy(b, Wi.data(), N * 16, hipMemcpyHostToDevice);
+        hipMemcpy(c, Wd.data(), N * 16, hipMemcpyHostToDevice); hipMemcpy(d, Wid.data(), N * 16, hipMemcpyHostToDevice);
+        LT[l].W = a; LT[l].Winv = b; LT[l].Wd = c; LT[l].Winvd = d;
+    }
+    ntt_limb_t* dLT; hipMalloc(&dLT, L * sizeof(ntt_limb_t)); hipMemcpy(dLT, LT.data(), L * sizeof(ntt_limb_t), hipMemcpyHostToDevice);
+    u64 *d_a, *d_b; hipMalloc(&d_a, (size_t)rows * N * 8); hipMalloc(&d_b, (size_t)rows * N * 8);
+    std::vector<u64> h((size_t)rows * N);
+    u64 s = 88172645463325252ull;
+    for (auto& x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = s % ((1ull << 50) + 1); }
+    hipMemcpy(d_a, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    run<ArithFp>("fwd fp64", dLT, L, d_a, d_b, rows, false);
+    run<ArithFp>("inv fp64", dLT, L, d_a, d_b, rows, true);
+    run<ArithInt>("fwd u64", dLT, L, d_a, d_b, rows, false);
+    run<ArithInt>("inv u64", dLT, L, d_a, d_b, rows, true);
+    return 0;
+}

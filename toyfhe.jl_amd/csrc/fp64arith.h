@@ -1,0 +1,57 @@
+// fp64arith.h -- modular arithmetic on exact integers held in IEEE doubles, for primes p < 1.125 * 2^50.
+//
+// Why: on gfx950 a 64-bit Shoup butterfly costs ten 32-bit multiplier ops (v_mad_u64_u32 / v_mul_lo /
+// v_mul_hi, 4 cycles per wave64 each) plus carry chains; v_fma_f64 / v_mul_f64 / v_rndne_f64 issue at
+// the same 4 cycles, and a constant-operand modular product is 6 of them (gpurun_out/microbench.txt).
+// All results are exact integers -- fma-based error-free transformations, no rounding anywhere that
+// matters -- so the transform stays bit-identical to the integer path (checked against the oracle).
+//
+//   mulmod_c(y; w):  h = fl(w y), l = fma(w, y, -h)              (h + l = w y exactly)
+//                     k = rint(fl(h * fl(1/p)))                   (|k - w y / p| <= 1/2 + 1.5 |y| 2^-52)
+//                     r = fma(-k, p, h) + l                       (exact: |r| <= p (1/2 + 1.5 |y| 2^-52) < 2^53)
+// A twiddle is ONE double (8 bytes in the table, 2 VGPRs).  Values are kept as signed lazy
+// representatives; `reduce` brings |v| back to <= p/2 (+ tiny).
+// Range bookkeeping (in units of p, a = p 2^-52 <= 0.28125, growth per forward stage b' = b (1 + 1.5 a) + 1/2):
+//   forward, from |v| <= 1/2 (LDS values are reduced, global inputs are centred):
+//        1.21, 2.22, 3.66, 5.70 after 1..4 stages  < 2^53 / p >= 7.1;  5-stage passes reduce after stage 3
+//   inverse, reduce after every second stage: sums double (1/2 -> 2), products stay <= 1.4
+#pragma once
+#include "modarith.h"
+
+#define TFHE_FP_QMAX 1266637395197952ull /* 1.125 * 2^50 */
+
+struct ftw_t {  // twiddle w, an exact integer < p
+    double w;
+};
+typedef double ftwd_t;  // table entry
+
+TFHE_HD double fp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+TFHE_HD double fp_rint(double x) { return __builtin_rint(x); }
+
+TFHE_HD double fp_mulmod_c(double y, ftw_t t, double p, double pinv) {
+    const double h = t.w * y;
+    const double l = fp_fma(t.w, y, -h);
+    const double k = fp_rint(h * pinv);
+    return fp_fma(-k, p, h) + l;
+}
+TFHE_HD double fp_reduce(double v, double p, double pinv) { return fp_fma(-fp_rint(v * pinv), p, v); }
+
+// exact conversions for 0 <= x < 2^52
+TFHE_HD double fp_from_u64(u64 x) {
+    const u64 bits = x | 0x4330000000000000ull;  // 2^52 + x
+    double d;
+    __builtin_memcpy(&d, &bits, 8);
+    return d - 4503599627370496.0;
+}
+TFHE_HD u64 fp_to_u64(double v) {  // v an integer in [0, 2^52)
+    const double d = v + 4503599627370496.0;
+    u64 bits;
+    __builtin_memcpy(&bits, &d, 8);
+    return bits & 0x000fffffffffffffull;
+}
+// canonical residue in [0, p) of a lazy value
+TFHE_HD u64 fp_canon(double v, double p, double pinv) {
+    double r = fp_reduce(v, p, pinv);
+    r = r < 0.0 ? r + p : r;
+    return fp_to_u64(r);
+}

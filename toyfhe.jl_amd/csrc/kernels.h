@@ -15,54 +15,66 @@ struct limb_sel_t {  // which context modulus each buffer limb uses (crtselect, 
 // NTT: register-blocked LDS kernel.  Block b = ((poly*limbs + j) << x) + sb handles sub-block sb of
 // limb j of polynomial `poly`; x = log2(N) - LOGB (0 when the whole limb fits one LDS block).
 // ------------------------------------------------------------------------------------------------
-constexpr int pass_k_fwd(int logb, int s0) { return (logb - s0) >= 4 ? 4 : (logb - s0); }
-constexpr int pass_k_inv(int s_end) { return (s_end % 4) ? (s_end % 4) : 4; }
 
-template <int LOGB, int LOGT, int S0>
-__device__ __forceinline__ void fwd_schedule(u64* lds, const u64* gsrc, u64* gdst, const twd_t* W, u64 q, u32 tid,
+// ---- simple schedule: one workgroup per item, passes separated by barriers ----
+template <class A, int LOGB, int LOGT, int S0>
+__device__ __forceinline__ void fwd_schedule(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
                                              u32 pre, int x, u32 sbrev) {
-    constexpr int K = pass_k_fwd(LOGB, S0);
+    constexpr int K = pass_k_fwd(LOGB, LOGT, S0);
     constexpr bool LAST = (S0 + K == LOGB);
-    ntt_fwd_pass<LOGB, LOGT, S0, K, S0 == 0, LAST>(lds, gsrc, gdst, W, q, tid, pre, x, sbrev);
+    ntt_fwd_pass<A, LOGB, LOGT, S0, K, S0 == 0, LAST>(lds, gsrc, gdst, C, tid, pre, x, sbrev);
     if constexpr (!LAST) {
         __syncthreads();
-        fwd_schedule<LOGB, LOGT, S0 + K>(lds, gsrc, gdst, W, q, tid, pre, x, sbrev);
+        fwd_schedule<A, LOGB, LOGT, S0 + K>(lds, gsrc, gdst, C, tid, pre, x, sbrev);
     }
 }
-template <int LOGB, int LOGT, int SEND, bool SCALE>
-__device__ __forceinline__ void inv_schedule(u64* lds, const u64* gsrc, u64* gdst, const ntt_limb_t& L, u32 tid, u32 pre,
-                                             int x, u32 sbrev) {
-    constexpr int K = pass_k_inv(SEND);
+template <class A, int LOGB, int LOGT, int SEND, bool SCALE>
+__device__ __forceinline__ void inv_schedule(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
+                                             u32 pre, int x, u32 sbrev) {
+    constexpr int K = pass_k_inv(LOGB, LOGT, SEND);
     constexpr int S0 = SEND - K;
-    ntt_inv_pass<LOGB, LOGT, S0, K, SEND == LOGB, S0 == 0, SCALE>(lds, gsrc, gdst, L, tid, pre, x, sbrev);
+    ntt_inv_pass<A, LOGB, LOGT, S0, K, SEND == LOGB, S0 == 0, SCALE>(lds, gsrc, gdst, C, tid, pre, x, sbrev);
     if constexpr (S0 != 0) {
         __syncthreads();
-        inv_schedule<LOGB, LOGT, S0, SCALE>(lds, gsrc, gdst, L, tid, pre, x, sbrev);
+        inv_schedule<A, LOGB, LOGT, S0, SCALE>(lds, gsrc, gdst, C, tid, pre, x, sbrev);
     }
 }
 
-template <int LOGB, int LOGT>
+// Workgroups loop over items i = blockIdx.x, blockIdx.x + gridDim.x, ... (item = ((poly*limbs + j) << x) + sb).
+template <class A, int LOGB, int LOGT>
 __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_block(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                              const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x) {
+                                                              const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
+                                                              u32 nitems) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const u32 b = blockIdx.x, sb = b & ((1u << x) - 1), pl = b >> x;
-    const ntt_limb_t L = LT[sel.idx[pl % (u32)sel.n]];
     const size_t ntot = (size_t)1 << (LOGB + x);
-    fwd_schedule<LOGB, LOGT, 0>(lds, src + pl * ntot + ((size_t)sb << LOGB), dst + pl * ntot, L.W, L.q, threadIdx.x,
-                                (1u << x) + sb, x, brev_bits(sb, x));
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const u32 sb = item & ((1u << x) - 1), pl = item >> x;
+        const typename A::ctx C = A::make(LT[sel.idx[pl % (u32)sel.n]]);
+        if (item != blockIdx.x) __syncthreads();  // the previous item's last pass has read LDS
+        fwd_schedule<A, LOGB, LOGT, 0>(lds, src + pl * ntot + ((size_t)sb << LOGB), dst + pl * ntot, C, threadIdx.x,
+                                       (1u << x) + sb, x, brev_bits(sb, x));
+    }
 }
-template <int LOGB, int LOGT>
+template <class A, int LOGB, int LOGT>
 __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                              const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x) {
+                                                              const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
+                                                              u32 nitems) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const u32 b = blockIdx.x, sb = b & ((1u << x) - 1), pl = b >> x;
-    const ntt_limb_t L = LT[sel.idx[pl % (u32)sel.n]];
     const size_t ntot = (size_t)1 << (LOGB + x);
-    if (x == 0)
-        inv_schedule<LOGB, LOGT, LOGB, true>(lds, src + pl * ntot, dst + pl * ntot, L, threadIdx.x, 1u, 0, 0u);
-    else
-        inv_schedule<LOGB, LOGT, LOGB, false>(lds, src + pl * ntot, dst + pl * ntot + ((size_t)sb << LOGB), L,
-                                              threadIdx.x, (1u << x) + sb, x, brev_bits(sb, x));
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const u32 sb = item & ((1u << x) - 1), pl = item >> x;
+        const typename A::ctx C = A::make(LT[sel.idx[pl % (u32)sel.n]]);
+        if (item != blockIdx.x) __syncthreads();
+        if constexpr (A::whole_block_only) {  // the fp64 variant is only dispatched for x == 0
+            inv_schedule<A, LOGB, LOGT, LOGB, true>(lds, src + pl * ntot, dst + pl * ntot, C, threadIdx.x, 1u, 0, 0u);
+        } else {
+            if (x == 0)
+                inv_schedule<A, LOGB, LOGT, LOGB, true>(lds, src + pl * ntot, dst + pl * ntot, C, threadIdx.x, 1u, 0, 0u);
+            else
+                inv_schedule<A, LOGB, LOGT, LOGB, false>(lds, src + pl * ntot, dst + pl * ntot + ((size_t)sb << LOGB), C,
+                                                         threadIdx.x, (1u << x) + sb, x, brev_bits(sb, x));
+        }
+    }
 }
 
 // top stages of N > 2^LOGB transforms: one column per thread, rows = count*limbs

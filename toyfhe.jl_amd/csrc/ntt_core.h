@@ -16,7 +16,16 @@
 // The functions are written against a flat `lds` array so that tests/emul/ can run the very same
 // index logic on the CPU (looping over thread ids between barriers).
 #pragma once
+#include "fp64arith.h"
 #include "modarith.h"
+
+// compiler-level fence: keeps loads from being hoisted above it (register pressure control in the
+// software-pipelined kernels); nothing at run time
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TFHE_SCHED_FENCE() asm volatile("" ::: "memory")
+#else
+#define TFHE_SCHED_FENCE() ((void)0)
+#endif
 
 struct alignas(16) twd_t {  // twiddle (w, floor(w 2^64 / q)) -- one 16-byte load
     u64 w, wp;
@@ -35,13 +44,24 @@ TFHE_HD tw_t ld_tw(const twd_t* tab, u32 i) {
 #endif
 }
 
-// Padded LDS layout (word = 8 bytes).  Chosen with tools/lds_conflict_sim.py: for LOGB=14,
-// 1024 threads, passes 4/4/4/2 every ds_read_b64/ds_write_b64 of every pass is conflict-free
-// except the bit-reversed group access of the boundary pass (2-way on writes).
-TFHE_HD u32 lds_phi(u32 j) { return j + 4u * (j >> 6) + (j >> 9); }
-constexpr u32 lds_words(int logb) {
-    return ((1u << logb) - 1) + 4u * (((1u << logb) - 1) >> 6) + (((1u << logb) - 1) >> 9) + 1;
+// Padded LDS layouts (word = 8 bytes), chosen with tools/lds_conflict_sim.py so that the ds_read_b64 /
+// ds_write_b64 of every pass are bank-conflict free:
+//   32 elements per thread (LOGB = 14: 512 threads, passes 5/5/4):  phi(j) = j + 2*(j>>6) + (j>>10)
+//   16 elements per thread (LOGB <= 13, passes 4/4/..):              phi(j) = j + 4*(j>>6) + (j>>9)
+template <int LOGB, int LOGT>
+TFHE_HD u32 lds_phi(u32 j) {
+    if (LOGB - LOGT == 5) return j + 2u * (j >> 6) + (j >> 10);
+    return j + 4u * (j >> 6) + (j >> 9);
 }
+template <int LOGB, int LOGT>
+constexpr u32 lds_words() {
+    constexpr u32 m = (1u << LOGB) - 1;
+    return (LOGB - LOGT == 5) ? (m + 2u * (m >> 6) + (m >> 10) + 1) : (m + 4u * (m >> 6) + (m >> 9) + 1);
+}
+// elements per thread and pass partition (K stages per pass, at most log2(E))
+constexpr int logt_for(int logb) { return logb >= 14 ? logb - 5 : logb - 4; }
+constexpr int pass_k_fwd(int logb, int logt, int s0) { return (logb - s0) >= (logb - logt) ? (logb - logt) : (logb - s0); }
+constexpr int pass_k_inv(int logb, int logt, int s_end) { return (s_end % (logb - logt)) ? (s_end % (logb - logt)) : (logb - logt); }
 
 // Harvey butterflies.  Forward keeps values in [0,4q); inverse keeps them in [0,2q).
 TFHE_HD void bfly_fwd(u64& x, u64& y, tw_t w, u64 q) {
@@ -64,119 +84,325 @@ struct ntt_limb_t {   // per-limb constants (device copy lives in the context)
     barrett_t br;     // for products of two variable operands
     const twd_t* W;     // forward table, N entries (entry 0 unused)
     const twd_t* Winv;  // inverse table
+    // fp64 variant (q < TFHE_FP_QMAX only; Wd == nullptr otherwise)
+    double pd, pinvd;
+    ftw_t ninv_d, w1inv_ninv_d;
+    const ftwd_t* Wd;
+    const ftwd_t* Winvd;
 };
 
 // ---------------------------------------------------------------------------------------------
-// One forward pass: stages S0 .. S0+K-1 of a 2^LOGB block on 2^K registers per set.
-//   FIRST: operands come from global memory (block-local natural order, coalesced).
-//   LAST : results go to global memory in natural NTT order; the thread->group map is bit-reversed
-//          so that the 8-byte stores of a wavefront are contiguous.
+// Arithmetic policies for the block passes: the index logic is shared, the element type and the
+// butterfly differ.  ArithInt: u64 Harvey/Shoup (any q < 2^62).  ArithFp: exact integers in doubles
+// (q < TFHE_FP_QMAX), see fp64arith.h.
+// ---------------------------------------------------------------------------------------------
+struct ArithInt {
+    static constexpr bool whole_block_only = false;
+    typedef u64 elem;
+    typedef tw_t tw;
+    struct ctx {
+        u64 q;
+        const twd_t *W, *Winv;
+        tw_t ninv, w1n;
+    };
+    static TFHE_HD ctx make(const ntt_limb_t& L) { return ctx{L.q, L.W, L.Winv, L.ninv, L.w1inv_ninv}; }
+    static TFHE_HD elem from_global(u64 x, const ctx&) { return x; }
+    static TFHE_HD elem from_lds(u64 x) { return x; }
+    static TFHE_HD u64 to_lds(elem v) { return v; }
+    static TFHE_HD tw ld_fwd(const ctx& c, u32 i) { return ld_tw(c.W, i); }
+    static TFHE_HD tw ld_inv(const ctx& c, u32 i) { return ld_tw(c.Winv, i); }
+    static TFHE_HD void bf_fwd(elem& x, elem& y, tw w, const ctx& c) { bfly_fwd(x, y, w, c.q); }
+    static TFHE_HD void bf_inv(elem& x, elem& y, tw w, const ctx& c) { bfly_inv(x, y, w, c.q); }
+    static TFHE_HD void bf_inv_scaled(elem& x, elem& y, const ctx& c) {
+        const u64 a = x + y, d = x + 2 * c.q - y;
+        x = shoup_lazy(a, c.ninv, c.q);
+        y = shoup_lazy(d, c.w1n, c.q);
+    }
+    static TFHE_HD void range_fwd(elem&, const ctx&) {}
+    static TFHE_HD void range_inv(elem&, const ctx&) {}
+    static TFHE_HD u64 out_fwd(elem v, const ctx& c) { return csub(csub(v, 2 * c.q), c.q); }
+    static TFHE_HD u64 out_inv_scaled(elem v, const ctx& c) { return csub(v, c.q); }
+    static TFHE_HD u64 out_inv_lazy(elem v, const ctx&) { return v; }  // [0,2q) for the top kernel
+};
+
+struct ArithFp {
+    static constexpr bool whole_block_only = true;
+    typedef double elem;
+    typedef ftw_t tw;
+    struct ctx {
+        double p, pinv;
+        const ftwd_t *W, *Winv;
+        ftw_t ninv, w1n;
+    };
+    static TFHE_HD ctx make(const ntt_limb_t& L) { return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.ninv_d, L.w1inv_ninv_d}; }
+    // centred representative: keeps |v| <= p/2 at the start of the first pass (range budget of a 5-stage pass)
+    static TFHE_HD elem from_global(u64 x, const ctx& c) {
+        const double d = fp_from_u64(x);
+        return d + d > c.p ? d - c.p : d;
+    }
+    static TFHE_HD elem from_lds(u64 x) { double d; __builtin_memcpy(&d, &x, 8); return d; }
+    static TFHE_HD u64 to_lds(elem v) { u64 b; __builtin_memcpy(&b, &v, 8); return b; }
+    static TFHE_HD tw ld(const ftwd_t* tab, u32 i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(1))) const ftwd_t* gptr_t;
+        const gptr_t g = (gptr_t)tab;
+        return ftw_t{g[i]};
+#else
+        return ftw_t{tab[i]};
+#endif
+    }
+    static TFHE_HD tw ld_fwd(const ctx& c, u32 i) { return ld(c.W, i); }
+    static TFHE_HD tw ld_inv(const ctx& c, u32 i) { return ld(c.Winv, i); }
+    static TFHE_HD void bf_fwd(elem& x, elem& y, tw w, const ctx& c) {
+        const double t = fp_mulmod_c(y, w, c.p, c.pinv);
+        y = x - t;
+        x = x + t;
+    }
+    static TFHE_HD void bf_inv(elem& x, elem& y, tw w, const ctx& c) {
+        const double a = x + y, d = x - y;
+        x = a;
+        y = fp_mulmod_c(d, w, c.p, c.pinv);
+    }
+    static TFHE_HD void bf_inv_scaled(elem& x, elem& y, const ctx& c) {
+        const double a = x + y, d = x - y;
+        x = fp_mulmod_c(a, c.ninv, c.p, c.pinv);
+        y = fp_mulmod_c(d, c.w1n, c.p, c.pinv);
+    }
+    static TFHE_HD void range_fwd(elem& v, const ctx& c) { v = fp_reduce(v, c.p, c.pinv); }
+    static TFHE_HD void range_inv(elem& v, const ctx& c) { v = fp_reduce(v, c.p, c.pinv); }
+    static TFHE_HD u64 out_fwd(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
+    static TFHE_HD u64 out_inv_scaled(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
+    static TFHE_HD u64 out_inv_lazy(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Block passes.  A pass = stages S0 .. S0+K-1 of a 2^LOGB block, done by each thread on SETS register
+// sets of R = 2^K elements.  Each pass is split into four phases so that the kernels can software-
+// pipeline them (twiddles of pass p+1 and the data of the next polynomial are requested before the
+// barrier that ends pass p); the CPU emulation and the simple wrappers call them back to back.
+//   FIRST/FROM_GLOBAL: operands come from global memory.   LAST/TO_GLOBAL: results go to global memory.
+//   The pass that touches natural-order NTT data (forward LAST, inverse FROM_GLOBAL) uses a bit-reversed
+//   thread->group map so that the 8-byte accesses of a wavefront are contiguous (no bit-reversal pass).
 //   pre = 2^x + sb, where the block is sub-block sb of a 2^(LOGB+x)-point transform (x = 0, sb = 0,
 //   pre = 1 for N <= 2^LOGB); global stage index = x + local stage index.
 // ---------------------------------------------------------------------------------------------
-template <int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST>
-TFHE_HD void ntt_fwd_pass(u64* lds, const u64* gsrc, u64* gdst, const twd_t* W, u64 q, u32 tid, u32 pre, int x,
-                          u32 sb_rev) {
-    constexpr int T = 1 << LOGT, E = 1 << (LOGB - LOGT), R = 1 << K, SETS = E >> K, LO = LOGB - S0 - K;
+template <int LOGB, int LOGT, int S0, int K>
+struct pgeom {
+    static constexpr int T = 1 << LOGT, E = 1 << (LOGB - LOGT), R = 1 << K, SETS = E >> K, LO = LOGB - S0 - K;
+    static constexpr int NTW = R - 1;  // twiddles per set: stage d uses slots (1<<d)-1 .. (2<<d)-2
     static_assert(K >= 1 && (E >> K) >= 1, "pass wider than the per-thread register block");
-    static_assert(!LAST || LO == 0, "LAST pass must end at stage LOGB-1");
+    // coordinates of register set u of thread tid; BREV selects the bit-reversed group map
+    template <bool BREV>
+    static TFHE_HD void coords(u32 tid, int u, u32& c0, u32& hi, u32& base) {
+        c0 = (u32)u * T + tid;
+        const u32 c = BREV ? brev_bits(c0, LOGB - K) : c0;
+        const u32 lo = c & ((1u << LO) - 1);
+        hi = c >> LO;
+        base = (hi << (LOGB - S0)) + lo;
+    }
+};
+
+// ---- forward ----
+// twiddles of stages d in [D0, D1) of the pass (the kernels request the early stages before the barrier
+// that precedes the pass and the late ones, needed last, right after it)
+template <class A, int LOGB, int LOGT, int S0, int K, bool LAST, int D0 = 0, int D1 = K>
+TFHE_HD void fwd_load_tw(typename A::tw* tw, const typename A::ctx& C, u32 tid, u32 pre) {
+    typedef pgeom<LOGB, LOGT, S0, K> G;
 #pragma unroll
-    for (int u = 0; u < SETS; u++) {
-        const u32 c0 = (u32)u * T + tid;
-        const u32 c = LAST ? brev_bits(c0, LOGB - K) : c0;
-        const u32 lo = c & ((1u << LO) - 1), hi = c >> LO;
-        const u32 base = (hi << (LOGB - S0)) + lo;
-        u64 v[R];
+    for (int u = 0; u < G::SETS; u++) {
+        u32 c0, hi, base;
+        G::template coords<LAST>(tid, u, c0, hi, base);
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const u32 j = base + ((u32)r << LO);
-            v[r] = FIRST ? gsrc[j] : lds[lds_phi(j)];
+        for (int d = D0; d < D1; d++)
+#pragma unroll
+            for (int g = 0; g < (1 << d); g++)
+                tw[u * G::NTW + (1 << d) - 1 + g] = A::ld_fwd(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
+    }
+}
+// raw 64-bit words of the operands (global: residues; LDS: the policy's element bits)
+template <int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST>
+TFHE_HD void fwd_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid) {
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+#pragma unroll
+    for (int u = 0; u < G::SETS; u++) {
+        u32 c0, hi, base;
+        G::template coords<LAST>(tid, u, c0, hi, base);
+#pragma unroll
+        for (int r = 0; r < G::R; r++) {
+            const u32 j = base + ((u32)r << G::LO);
+            raw[u * G::R + r] = FIRST ? gsrc[j] : lds[lds_phi<LOGB, LOGT>(j)];
         }
+    }
+}
+// Butterflies of the pass.  Twiddles of stages d < PF come from `twp` (requested ahead by the caller);
+// the others are loaded here (the compiler schedules those loads).
+template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int PF>
+TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
+                         u32 pre) {
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+#pragma unroll
+    for (int u = 0; u < G::SETS; u++) {
+        u32 c0, hi, base;
+        G::template coords<LAST>(tid, u, c0, hi, base);
+        typename A::elem* vv = v + u * G::R;
+#pragma unroll
+        for (int r = 0; r < G::R; r++) vv[r] = FIRST ? A::from_global(raw[u * G::R + r], C) : A::from_lds(raw[u * G::R + r]);
 #pragma unroll
         for (int d = 0; d < K; d++) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int half = 1 << (K - 1 - d);
 #pragma unroll
             for (int g = 0; g < (1 << d); g++) {
-                const tw_t w = ld_tw(W, (pre << (S0 + d)) + (hi << d) + (u32)g);
+                const typename A::tw w = d < PF ? twp[u * G::NTW + (1 << d) - 1 + g]
+                                                : A::ld_fwd(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
 #pragma unroll
                 for (int i = 0; i < half; i++) {
                     const int r0 = (g << (K - d)) + i;
-                    bfly_fwd(v[r0], v[r0 + half], w, q);
+                    A::bf_fwd(vv[r0], vv[r0 + half], w, C);
                 }
             }
-        }
+            if (K >= 5 && d == 2) {  // range control inside 5-stage passes (fp64 budget; no-op for u64)
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            if (LAST) {
-                const u32 nat = (brev_bits((u32)r, K) << (LOGB - K)) + c0;  // brv_LOGB(block-local position)
-                gdst[((u64)nat << x) + sb_rev] = csub(csub(v[r], 2 * q), q);
-            } else {
-                lds[lds_phi(base + ((u32)r << LO))] = v[r];
+                for (int r = 0; r < G::R; r++) A::range_fwd(vv[r], C);
             }
         }
     }
 }
-
-// One inverse pass (mirror image).  FROM_GLOBAL: reads natural-order NTT values (S0+K == LOGB).
-// TO_GLOBAL: writes block-local natural coefficient order (S0 == 0); SCALE folds N^-1 into the last
-// stage (only when this block is the whole transform, x == 0).
-template <int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool TO_GLOBAL, bool SCALE>
-TFHE_HD void ntt_inv_pass(u64* lds, const u64* gsrc, u64* gdst, const ntt_limb_t& L, u32 tid, u32 pre, int x,
-                          u32 sb_rev) {
-    constexpr int T = 1 << LOGT, E = 1 << (LOGB - LOGT), R = 1 << K, SETS = E >> K, LO = LOGB - S0 - K;
-    static_assert(!FROM_GLOBAL || LO == 0, "FROM_GLOBAL pass must start at stage LOGB-1");
-    static_assert(!TO_GLOBAL || S0 == 0, "TO_GLOBAL pass must end at stage 0");
-    const u64 q = L.q;
+template <class A, int LOGB, int LOGT, int S0, int K, bool LAST>
+TFHE_HD void fwd_store(typename A::elem* v, u64* lds, u64* gdst, const typename A::ctx& C, u32 tid, int x, u32 sb_rev) {
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+    static_assert(!LAST || G::LO == 0, "LAST pass must end at stage LOGB-1");
 #pragma unroll
-    for (int u = 0; u < SETS; u++) {
-        const u32 c0 = (u32)u * T + tid;
-        const u32 c = FROM_GLOBAL ? brev_bits(c0, LOGB - K) : c0;
-        const u32 lo = c & ((1u << LO) - 1), hi = c >> LO;
-        const u32 base = (hi << (LOGB - S0)) + lo;
-        u64 v[R];
+    for (int u = 0; u < G::SETS; u++) {
+        u32 c0, hi, base;
+        G::template coords<LAST>(tid, u, c0, hi, base);
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            if (FROM_GLOBAL) {
-                const u32 nat = (brev_bits((u32)r, K) << (LOGB - K)) + c0;
-                v[r] = gsrc[((u64)nat << x) + sb_rev];
+        for (int r = 0; r < G::R; r++) {
+            typename A::elem e = v[u * G::R + r];
+            if (LAST) {
+                const u32 nat = (brev_bits((u32)r, K) << (LOGB - K)) + c0;  // brv_LOGB(block-local position)
+                gdst[((u64)nat << x) + sb_rev] = A::out_fwd(e, C);
             } else {
-                v[r] = lds[lds_phi(base + ((u32)r << LO))];
+                A::range_fwd(e, C);
+                lds[lds_phi<LOGB, LOGT>(base + ((u32)r << G::LO))] = A::to_lds(e);
             }
         }
+    }
+}
+template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST>
+TFHE_HD void ntt_fwd_pass(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid, u32 pre, int x,
+                          u32 sb_rev) {
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+    u64 raw[G::E];
+    typename A::elem v[G::E];
+    fwd_load_data<LOGB, LOGT, S0, K, FIRST, LAST>(raw, lds, gsrc, tid);
+    fwd_compute<A, LOGB, LOGT, S0, K, FIRST, LAST, 0>(v, raw, nullptr, C, tid, pre);
+    fwd_store<A, LOGB, LOGT, S0, K, LAST>(v, lds, gdst, C, tid, x, sb_rev);
+}
+
+// ---- inverse (mirror image).  SCALE folds N^-1 into the last stage (whole-transform blocks, x == 0). ----
+template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, int D0 = 0, int D1 = K>
+TFHE_HD void inv_load_tw(typename A::tw* tw, const typename A::ctx& C, u32 tid, u32 pre) {
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+#pragma unroll
+    for (int u = 0; u < G::SETS; u++) {
+        u32 c0, hi, base;
+        G::template coords<FROM_GLOBAL>(tid, u, c0, hi, base);
+#pragma unroll
+        for (int d = D0; d < D1; d++)
+#pragma unroll
+            for (int g = 0; g < (1 << d); g++)
+                tw[u * G::NTW + (1 << d) - 1 + g] = A::ld_inv(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
+    }
+}
+template <int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL>
+TFHE_HD void inv_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, int x, u32 sb_rev) {
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+    static_assert(!FROM_GLOBAL || G::LO == 0, "FROM_GLOBAL pass must start at stage LOGB-1");
+#pragma unroll
+    for (int u = 0; u < G::SETS; u++) {
+        u32 c0, hi, base;
+        G::template coords<FROM_GLOBAL>(tid, u, c0, hi, base);
+#pragma unroll
+        for (int r = 0; r < G::R; r++) {
+            if (FROM_GLOBAL) {
+                const u32 nat = (brev_bits((u32)r, K) << (LOGB - K)) + c0;
+                raw[u * G::R + r] = gsrc[((u64)nat << x) + sb_rev];
+            } else {
+                raw[u * G::R + r] = lds[lds_phi<LOGB, LOGT>(base + ((u32)r << G::LO))];
+            }
+        }
+    }
+}
+// Inverse butterflies (stage K-1 first).  Stages d >= K-PF come from `twp`; the others are loaded here.
+template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE, int PF>
+TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
+                         u32 pre) {
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+#pragma unroll
+    for (int u = 0; u < G::SETS; u++) {
+        u32 c0, hi, base;
+        G::template coords<FROM_GLOBAL>(tid, u, c0, hi, base);
+        typename A::elem* vv = v + u * G::R;
+#pragma unroll
+        for (int r = 0; r < G::R; r++)
+            vv[r] = FROM_GLOBAL ? A::from_global(raw[u * G::R + r], C) : A::from_lds(raw[u * G::R + r]);
 #pragma unroll
         for (int d = K - 1; d >= 0; d--) {
             const int half = 1 << (K - 1 - d);
 #pragma unroll
             for (int g = 0; g < (1 << d); g++) {
-                if (SCALE && TO_GLOBAL && d == 0) {
+                if (SCALE && S0 == 0 && d == 0) {
 #pragma unroll
-                    for (int i = 0; i < half; i++) {
-                        const int r0 = i;
-                        const u64 a = v[r0] + v[r0 + half], dd = v[r0] + 2 * q - v[r0 + half];
-                        v[r0] = shoup_lazy(a, L.ninv, q);
-                        v[r0 + half] = shoup_lazy(dd, L.w1inv_ninv, q);
-                    }
+                    for (int i = 0; i < half; i++) A::bf_inv_scaled(vv[i], vv[i + half], C);
                 } else {
-                    const tw_t w = ld_tw(L.Winv, (pre << (S0 + d)) + (hi << d) + (u32)g);
+                    const typename A::tw w = d >= K - PF ? twp[u * G::NTW + (1 << d) - 1 + g]
+                                                         : A::ld_inv(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
 #pragma unroll
                     for (int i = 0; i < half; i++) {
                         const int r0 = (g << (K - d)) + i;
-                        bfly_inv(v[r0], v[r0 + half], w, q);
+                        A::bf_inv(vv[r0], vv[r0 + half], w, C);
                     }
                 }
             }
-        }
+            // range control after every second processed stage (pass ends are handled by the store)
+            if (((K - 1 - d) & 1) == 1 && d != 0) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const u32 j = base + ((u32)r << LO);
-            if (TO_GLOBAL)
-                gdst[j] = SCALE ? csub(v[r], q) : v[r];  // unscaled blocks stay lazy in [0,2q) for the top kernel
-            else
-                lds[lds_phi(j)] = v[r];
+                for (int r = 0; r < G::R; r++) A::range_inv(vv[r], C);
+            }
         }
     }
+}
+template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE>
+TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename A::ctx& C, u32 tid) {
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+    constexpr bool TO_GLOBAL = (S0 == 0);
+#pragma unroll
+    for (int u = 0; u < G::SETS; u++) {
+        u32 c0, hi, base;
+        G::template coords<FROM_GLOBAL>(tid, u, c0, hi, base);
+#pragma unroll
+        for (int r = 0; r < G::R; r++) {
+            const u32 j = base + ((u32)r << G::LO);
+            typename A::elem e = v[u * G::R + r];
+            if (TO_GLOBAL) {
+                gdst[j] = SCALE ? A::out_inv_scaled(e, C) : A::out_inv_lazy(e, C);
+            } else {
+                A::range_inv(e, C);
+                lds[lds_phi<LOGB, LOGT>(j)] = A::to_lds(e);
+            }
+        }
+    }
+}
+template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool TO_GLOBAL, bool SCALE>
+TFHE_HD void ntt_inv_pass(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid, u32 pre, int x,
+                          u32 sb_rev) {
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+    static_assert(TO_GLOBAL == (S0 == 0), "TO_GLOBAL pass is the one ending at stage 0");
+    u64 raw[G::E];
+    typename A::elem v[G::E];
+    inv_load_data<LOGB, LOGT, S0, K, FROM_GLOBAL>(raw, lds, gsrc, tid, x, sb_rev);
+    inv_compute<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE, 0>(v, raw, nullptr, C, tid, pre);
+    inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid);
 }
 
 // ---------------------------------------------------------------------------------------------

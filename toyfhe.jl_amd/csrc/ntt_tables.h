@@ -8,7 +8,8 @@
 #include "ntt_core.h"
 
 // returns 0, or -1 if psi is not a primitive 2N-th root of unity mod q
-inline int build_ntt_tables(int64_t N, u64 q, u64 psi, std::vector<twd_t>& W, std::vector<twd_t>& Wi, ntt_limb_t* L) {
+inline int build_ntt_tables(int64_t N, u64 q, u64 psi, std::vector<twd_t>& W, std::vector<twd_t>& Wi, ntt_limb_t* L,
+                            std::vector<ftwd_t>* Wd = nullptr, std::vector<ftwd_t>* Wid = nullptr) {
     using namespace hostmath;
     int logN = 0;
     while ((1ll << logN) < N) logN++;
@@ -38,5 +39,22 @@ inline int build_ntt_tables(int64_t N, u64 q, u64 psi, std::vector<twd_t>& W, st
     L->br = make_barrett(q);
     L->W = W.data();
     L->Winv = Wi.data();
+    // fp64 variant: every table value is an exact integer < 2^51 held in a double
+    L->pd = (double)q;
+    L->pinvd = 1.0 / (double)q;
+    L->Wd = nullptr;
+    L->Winvd = nullptr;
+    if (q < TFHE_FP_QMAX && Wd && Wid) {
+        Wd->resize((size_t)N);
+        Wid->resize((size_t)N);
+        for (int64_t k = 0; k < N; k++) {
+            (*Wd)[k] = (double)W[k].w;
+            (*Wid)[k] = (double)Wi[k].w;
+        }
+        L->ninv_d = ftw_t{(double)L->ninv.w};
+        L->w1inv_ninv_d = ftw_t{(double)L->w1inv_ninv.w};
+        L->Wd = Wd->data();
+        L->Winvd = Wid->data();
+    }
     return 0;
 }

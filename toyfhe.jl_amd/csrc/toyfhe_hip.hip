@@ -49,7 +49,8 @@ struct tfhe_ctx {
     std::vector<u64> q, psi;
     std::vector<ntt_limb_t> limbs_host;
     ntt_limb_t* limbs_dev = nullptr;
-    std::vector<twd_t*> tabs;  // device twiddle tables (W, Winv per limb)
+    std::vector<void*> tabs;   // device twiddle tables (W, Winv and their fp64 twins per limb)
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int variant = 0;
@@ -90,8 +91,6 @@ int make_sel(const tfhe_ctx* c, int limbs, const int32_t* idx, limb_sel_t* sel) 
     return TFHE_OK;
 }
 
-template <int LOGB>
-constexpr int logt_for() { return LOGB - 4; }  // 16 elements per thread
 
 template <typename K>
 int set_lds(K kern, size_t bytes) {
@@ -113,28 +112,43 @@ void prof_end(tfhe_ctx* c) {
     hipEventRecord(c->prof_pairs.back().b, c->stream);
 }
 
-template <int LOGB>
+bool sel_fp(const tfhe_ctx* c, const limb_sel_t& sel, int x) {
+    if (x != 0 || c->variant == 2) return false;
+    for (int j = 0; j < sel.n; j++)
+        if (!c->limbs_host[sel.idx[j]].Wd) return false;
+    return true;
+}
+
+template <class A, int LOGB>
 int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x) {
-    constexpr int LOGT = logt_for<LOGB>();
-    const size_t lds = (size_t)lds_words(LOGB) * 8;
-    auto kern = k_ntt_fwd_block<LOGB, LOGT>;
+    constexpr int LOGT = logt_for(LOGB);
+    const size_t lds = (size_t)lds_words<LOGB, LOGT>() * 8;
+    auto kern = k_ntt_fwd_block<A, LOGB, LOGT>;
     static bool attr_set = false;
     if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
+    // persistent workgroups: as many as are co-resident (LDS-limited), each loops over items
+    const unsigned items = (unsigned)(rows << x);
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(160 * 1024) / lds, (size_t)2048 >> LOGT}));
+    const unsigned grid = std::min(items, (unsigned)c->num_cus * per_cu);
     prof_begin(c, rows);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(rows << x)), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items);
     prof_end(c);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
-template <int LOGB>
+template <class A, int LOGB>
 int launch_block_inv(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x) {
-    constexpr int LOGT = logt_for<LOGB>();
-    const size_t lds = (size_t)lds_words(LOGB) * 8;
-    auto kern = k_ntt_inv_block<LOGB, LOGT>;
+    constexpr int LOGT = logt_for(LOGB);
+    const size_t lds = (size_t)lds_words<LOGB, LOGT>() * 8;
+    auto kern = k_ntt_inv_block<A, LOGB, LOGT>;
     static bool attr_set = false;
     if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
+    // persistent workgroups: as many as are co-resident (LDS-limited), each loops over items
+    const unsigned items = (unsigned)(rows << x);
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(160 * 1024) / lds, (size_t)2048 >> LOGT}));
+    const unsigned grid = std::min(items, (unsigned)c->num_cus * per_cu);
     prof_begin(c, rows);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(rows << x)), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items);
     prof_end(c);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
@@ -166,12 +180,15 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
     if (rows == 0) return TFHE_OK;
     if (rows < 0 || (rows << std::max(0, c->logN - 14)) > 0x7fffffffll) return fail(TFHE_E_BADARG, "bad polynomial count");
     const int n = c->logN;
-    const bool use_block = (c->variant == 0 && n >= 10) || n > 14;
+    const bool use_block = (c->variant != 1 && n >= 10) || n > 14;
     if (!use_block) return launch_generic(c, inverse, src, dst, rows, sel);
     if (n <= 14) {
+        const bool fp = sel_fp(c, sel, 0);
         switch (n) {
-#define CASE_(LB)                                                                                              \
-    case LB: return inverse ? launch_block_inv<LB>(c, src, dst, rows, sel, 0) : launch_block_fwd<LB>(c, src, dst, rows, sel, 0);
+#define CASE_(LB)                                                                                                  \
+    case LB:                                                                                                       \
+        if (fp) return inverse ? launch_block_inv<ArithFp, LB>(c, src, dst, rows, sel, 0) : launch_block_fwd<ArithFp, LB>(c, src, dst, rows, sel, 0); \
+        return inverse ? launch_block_inv<ArithInt, LB>(c, src, dst, rows, sel, 0) : launch_block_fwd<ArithInt, LB>(c, src, dst, rows, sel, 0);
             CASE_(10) CASE_(11) CASE_(12) CASE_(13) CASE_(14)
 #undef CASE_
         }
@@ -193,9 +210,9 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
         }
         prof_end(c);
         HIP_TRY(hipGetLastError());
-        return launch_block_fwd<14>(c, t, dst, rows, sel, x);
+        return launch_block_fwd<ArithInt, 14>(c, t, dst, rows, sel, x);
     }
-    rc = launch_block_inv<14>(c, src, t, rows, sel, x);
+    rc = launch_block_inv<ArithInt, 14>(c, src, t, rows, sel, x);
     if (rc) return rc;
     prof_begin(c, 0);
     switch (x) {
@@ -262,11 +279,12 @@ int tfhe_ctx_create(int64_t N, int L, const uint64_t* q, const uint64_t* psi, tf
     c->psi.resize(L);
     c->limbs_host.resize(L);
     std::vector<twd_t> W, Wi;
+    std::vector<ftwd_t> Wd, Wid;
     for (int l = 0; l < L; l++) {
         const u64 ql = q[l];
         u64 p = (psi && psi[l]) ? psi[l] : minimal_primitive_root(ql, 2 * (u64)N);
         ntt_limb_t& LL = c->limbs_host[l];
-        if (build_ntt_tables(N, ql, p, W, Wi, &LL) != 0) {  // pow2_cyc_rings.jl:31,61 (+ primitivity: psi^N == -1)
+        if (build_ntt_tables(N, ql, p, W, Wi, &LL, &Wd, &Wid) != 0) {  // pow2_cyc_rings.jl:31,61 (+ primitivity: psi^N == -1)
             tfhe_ctx_destroy(c);
             return fail(TFHE_E_BADARG, "psi[%d]=%llu is not a primitive 2N-th root of unity mod q[%d]", l, (unsigned long long)p, l);
         }
@@ -284,10 +302,27 @@ int tfhe_ctx_create(int64_t N, int L, const uint64_t* q, const uint64_t* psi, tf
         }
         LL.W = dW;
         LL.Winv = dWi;
+        if (LL.Wd) {  // fp64 twins of the tables
+            ftwd_t *fW = nullptr, *fWi = nullptr;
+            if (hipMalloc(&fW, N * sizeof(ftwd_t)) != hipSuccess || hipMalloc(&fWi, N * sizeof(ftwd_t)) != hipSuccess ||
+                hipMemcpy(fW, Wd.data(), N * sizeof(ftwd_t), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(fWi, Wid.data(), N * sizeof(ftwd_t), hipMemcpyHostToDevice) != hipSuccess) {
+                tfhe_ctx_destroy(c);
+                return fail(TFHE_E_HIP, "allocating fp64 twiddle tables failed");
+            }
+            c->tabs.push_back(fW); c->tabs.push_back(fWi);
+            LL.Wd = fW;
+            LL.Winvd = fWi;
+        }
     }
     if (hipMalloc(&c->limbs_dev, L * sizeof(ntt_limb_t)) != hipSuccess) { tfhe_ctx_destroy(c); return fail(TFHE_E_HIP, "hipMalloc failed"); }
     hipMemcpy(c->limbs_dev, c->limbs_host.data(), L * sizeof(ntt_limb_t), hipMemcpyHostToDevice);
     if (hipStreamCreate(&c->stream) != hipSuccess) { tfhe_ctx_destroy(c); return fail(TFHE_E_HIP, "hipStreamCreate failed"); }
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            c->num_cus = cus;
+    }
     c->own_stream = true;
     *out = c;
     return TFHE_OK;
@@ -324,7 +359,7 @@ int tfhe_ctx_sync(tfhe_ctx* c) {
     return TFHE_OK;
 }
 int tfhe_ctx_set_ntt_variant(tfhe_ctx* c, int v) {
-    if (!c || v < 0 || v > 1) return fail(TFHE_E_BADARG, "variant must be 0 or 1");
+    if (!c || v < 0 || v > 2) return fail(TFHE_E_BADARG, "variant must be 0, 1 or 2");
     c->variant = v;
     return TFHE_OK;
 }

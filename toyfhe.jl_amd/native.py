@@ -37,7 +37,7 @@ def build(force: bool = False) -> str:
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-shared", "-fPIC",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-shared", "-fPIC",
            os.path.join(_SRC, "toyfhe_hip.hip"), "-o", _SO]
     subprocess.check_call(cmd)
     return _SO
