@@ -129,6 +129,9 @@ int tfhe_bfv_contract(tfhe_bfv_plan *plan, const uint64_t *src, uint64_t *dst, i
  * relinearize" unit): out [batch][2][ns][N].  The key ring is ℛ itself (special == 0), which must be
  * limbs 0..ns-1 of the small ctx; evk: [n_digits][2][ns][N]. */
 int tfhe_bfv_mul_relin(tfhe_bfv_plan *plan, const uint64_t *evk, int n_digits, const uint64_t *c1, const uint64_t *c2, uint64_t *out, int64_t batch);
+/* expand/contract kernel family: 0 = auto (register-resident constant-folded kernels when ℛbig ⊇ ℛ and the
+ * limb counts are instantiated, else the general kernels), 1 = force the general kernels (cross-check). */
+int tfhe_bfv_plan_set_variant(tfhe_bfv_plan *plan, int variant);
 /* ciphertexts processed per internal chunk (workspace = chunk * 7 * nb * N * 8 bytes); 0 = default */
 int tfhe_bfv_plan_set_chunk(tfhe_bfv_plan *plan, int chunk);
 

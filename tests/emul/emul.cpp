@@ -159,4 +159,28 @@ int emul_bfv(const uint64_t* qs, int ns, const uint64_t* pb, int nb, uint64_t t,
     return 0;
 }
 
+// fast (register-resident, folded) BFV expand / contract; returns -9 if (ns, np) has no instantiation
+int emul_bfv_fast(const uint64_t* qs, int ns, const uint64_t* pb, int nb, uint64_t t, int contract, int64_t N,
+                  const uint64_t* src, uint64_t* dst, long count) {
+    bfv_fast_host_t* H = new bfv_fast_host_t();
+    if (!build_bfv_fast_host(std::vector<u64>(qs, qs + ns), std::vector<u64>(pb, pb + nb), t, H)) { delete H; return -7; }
+    const int np = H->tab.np;
+    int rc = 0;
+    for (long p = 0; p < count && !rc; p++)
+        for (int64_t k = 0; k < N; k++) {
+            const u64* s = contract ? src + p * nb * N + k : src + p * ns * N + k;
+            u64* d = contract ? dst + p * ns * N + k : dst + p * nb * N + k;
+#define FAST_(S, P_)                                                                           \
+    else if (ns == S && np == P_) {                                                            \
+        if (contract) bfv_contract_fast<S, P_>(H->tab, s, N, d, N); else bfv_expand_fast<S, P_>(H->tab, s, N, d, N); \
+    }
+            if (false) {}
+            FAST_(8, 9) FAST_(3, 4) FAST_(2, 3) FAST_(6, 7)
+            else { rc = -9; break; }
+#undef FAST_
+        }
+    delete H;
+    return rc;
+}
+
 }  // extern "C"

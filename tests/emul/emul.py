@@ -20,6 +20,7 @@ def lib():
         L.emul_conv.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_int, u64p, u64p, C.c_long]
         L.emul_bfv.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_uint64, C.c_int, C.c_int64, u64p, u64p, C.c_long,
                                C.POINTER(C.c_long)]
+        L.emul_bfv_fast.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_uint64, C.c_int, C.c_int64, u64p, u64p, C.c_long]
         _LIB = L
     return _LIB
 
@@ -57,3 +58,15 @@ def bfv(qs, pb, t, src, N, contract):
     if rc:
         raise RuntimeError(f"emul_bfv rc={rc}")
     return out, slow.value
+
+
+def bfv_fast(qs, pb, t, src, N, contract):
+    qs_a = np.array(qs, dtype=np.uint64); pb_a = np.array(pb, dtype=np.uint64)
+    src = np.ascontiguousarray(src, dtype=np.uint64)
+    nin, nout = (len(pb), len(qs)) if contract else (len(qs), len(pb))
+    count = src.size // (nin * N)
+    out = np.empty((count, nout, N), dtype=np.uint64)
+    rc = lib().emul_bfv_fast(_p(qs_a), len(qs), _p(pb_a), len(pb), int(t), int(contract), N, _p(src), _p(out), count)
+    if rc:
+        raise RuntimeError(f"emul_bfv_fast rc={rc}")
+    return out

@@ -250,7 +250,7 @@ def test_keyswitch_decrypts_ckks_modraise():
 # K12/K13: BFV
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["superset", "disjoint"])
-@pytest.mark.parametrize("N,bits,ns,nextra", [(32, 50, 3, 4), (2048, 50, 2, 3), (4096, 40, 2, 4), (1024, 60, 2, 3)])
+@pytest.mark.parametrize("N,bits,ns,nextra", [(32, 50, 3, 4), (2048, 50, 2, 3), (4096, 40, 2, 4), (1024, 60, 2, 3), (64, 50, 8, 9), (256, 61, 6, 7)])
 def test_bfv_expand_contract_mul(mode, N, bits, ns, nextra):
     t = 65537
     ch = H.chain(bits, 2 * ns + nextra + 1, N)
@@ -280,6 +280,13 @@ def test_bfv_expand_contract_mul(mode, N, bits, ns, nextra):
     dy, dc = dev(y), tf.DeviceBuffer(3 * ns * N)
     plan.contract(dy.ptr, dc.ptr, 3)
     assert np.array_equal(dc.to_numpy((3, ns, N)), ref_cpu.contract(rb, rs, t, y))
+    if mode == "superset":   # the general kernels must agree with the register-resident fast path (when instantiated)
+        plan.set_variant(1)
+        plan.expand(da.ptr, de.ptr, 4)
+        assert np.array_equal(de.to_numpy((4, len(pb), N)), ref_cpu.switch(rs, rb, a))
+        plan.contract(dy.ptr, dc.ptr, 3)
+        assert np.array_equal(dc.to_numpy((3, ns, N)), ref_cpu.contract(rb, rs, t, y))
+        plan.set_variant(0)
     batch = 5
     plan.set_chunk(2)   # exercise the chunked pipeline incl. a ragged last chunk
     c1, c2 = H.rand_residues(rng, qs, (batch, 2), N), H.rand_residues(rng, qs, (batch, 2), N)

@@ -169,3 +169,31 @@ def test_bfv_bodies_reject_partial_overlap():
     ch = _chain(50, 6, N)
     with pytest.raises(RuntimeError):
         emul.bfv(ch[:3], ch[1:6], 65537, np.zeros((1, 3, N), dtype=np.uint64), N, contract=False)
+
+
+@pytest.mark.parametrize("bits,ns,np_", [(50, 8, 9), (50, 3, 4), (40, 2, 3), (60, 3, 4), (61, 6, 7)])
+def test_bfv_fast_path_bodies(bits, ns, np_):
+    """bfv_fast.h (folded constants, register-resident) against the oracle, incl. edge values that force the
+    exact-alpha branch; ℛbig limb order shuffled."""
+    N, t = 32, 65537
+    ch = _chain(bits, ns + np_, N)
+    qs = ch[:ns]
+    pb = ch[ns:] + ch[:ns]          # P limbs first, shared limbs last
+    pb = pb[1:] + pb[:1]            # rotate: positions are arbitrary
+    cs, cb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, pb)
+    small, big = spec.Ring(N, qs), spec.Ring(N, pb)
+    rng = np.random.default_rng(bits + ns)
+    a = np.stack([rng.integers(0, q, size=(5, N), dtype=np.uint64) for q in qs], axis=1)
+    for k, x in enumerate([0, 1, small.Q - 1, small.Q // 2, small.Q // 2 + 1, 7, small.Q - 7]):
+        for l, q in enumerate(qs):
+            a[0, l, k] = x % q
+    assert np.array_equal(emul.bfv_fast(qs, pb, t, a, N, contract=False), ref_cpu.switch(cs, cb, a))
+    y = np.stack([rng.integers(0, p, size=(6, N), dtype=np.uint64) for p in pb], axis=1)
+    tinv = pow(t, -1, big.Q)
+    edges = [0, 1, big.Q - 1, big.Q // 2, big.Q // 2 + 1, small.Q // 2, small.Q // 2 + 1, small.Q, small.Q - 1,
+             3 * small.Q + small.Q // 2, 3 * small.Q + small.Q // 2 + 1, big.Q - small.Q // 2, big.Q - small.Q // 2 - 1,
+             small.Q * (big.Q // small.Q // 2), small.Q * (big.Q // small.Q // 2) + small.Q // 2 + 1]
+    for k, x in enumerate(edges):
+        for l, p in enumerate(pb):
+            y[0, l, k] = (x * tinv) % big.Q % p
+    assert np.array_equal(emul.bfv_fast(qs, pb, t, y, N, contract=True), ref_cpu.contract(cb, cs, t, y))

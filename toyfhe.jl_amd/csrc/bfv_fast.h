@@ -1,0 +1,162 @@
+// bfv_fast.h -- register-resident, constant-folded BFV expand / contract for ℛbig = ℛ ∪ P with compile-time
+// limb counts (NS limbs of ℛ, NP limbs of P).  Same exact results as bfv_core.h (which stays as the
+// general path and as the cross-check); what changes is the schedule:
+//   * every per-limb scalar factor (t, (q)^-1, (A/a_j)^-1, the centring offsets) is folded into the
+//     conversion matrices on the host, so a coefficient costs NS + NP Shoup products, 2*NS*NP 128-bit
+//     MACs and NS + NP Barrett reductions instead of ~3x that many modular products;
+//   * ξ lives in registers (loops are unrolled over NS / NP), constants are workgroup-uniform loads.
+// Reference semantics: src/bfv.jl:34-40,172-226 via src/crt.jl:91-112 (see bfv_core.h for the derivation).
+#pragma once
+#include "conv_core.h"
+
+template <int K>
+TFHE_HD u32 conv_alpha_fast(const u64 (&xi)[K], const u64* rho, const u32* sh, u64& frac_out) {
+    u64 frac = 0;
+    u32 carries = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const u64 xb = xi[j] << sh[j];
+        const u64 f = xb + mulhi64(xb, rho[j]);
+        const u64 s = frac + f;
+        carries += (s < f);
+        frac = s;
+    }
+    frac_out = frac;
+    return carries;
+}
+// exact decision of alpha (rare): is X = Σ ξ_j (A/a_j) >= (carries+1) A ?   (same algorithm as conv_prepare)
+template <int K>
+TFHE_HD u32 conv_alpha_exact(const u64 (&xi)[K], const u64* M, const u64* Aw, int nwords, u32 carries) {
+    const u64 mult = (u64)carries + 1;
+    u64 acc_lo = 0, acc_hi = 0, acc_ex = 0, mcarry = 0, borrow = 0;
+    for (int w = 0; w <= nwords; w++) {
+        if (w < nwords) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const u64 mw = M[(size_t)j * nwords + w];
+                const u64 lo = xi[j] * mw, hi = mulhi64(xi[j], mw);
+                u64 s = acc_lo + lo;
+                const u64 c = (s < lo);
+                acc_lo = s;
+                s = acc_hi + hi;
+                u64 c2 = (s < hi);
+                s += c;
+                c2 += (s < c);
+                acc_hi = s;
+                acc_ex += c2;
+            }
+        }
+        const u64 xw = acc_lo;
+        acc_lo = acc_hi; acc_hi = acc_ex; acc_ex = 0;
+        const u64 aw = w < nwords ? Aw[w] : 0;
+        const u64 plo = aw * mult, phi = mulhi64(aw, mult);
+        const u64 yw = plo + mcarry;
+        mcarry = phi + (yw < plo);
+        const u64 d = xw - yw;
+        borrow = (u64)(xw < yw) | (u64)(d < borrow);
+    }
+    return carries + (borrow ? 0u : 1u);
+}
+
+#define TFHE_FAST_MAX 12  // max NS / NP of the fast path tables
+
+struct bfv_fast_tab_t {
+    int ns, np, nb;
+    // ---- expand: x (basis q, centred) -> the NP limbs of P; the NS shared limbs are copied ----
+    int pos_s[TFHE_FAST_MAX], pos_p[TFHE_FAST_MAX];
+    u64 q[TFHE_FAST_MAX];
+    tw_t e_inv[TFHE_FAST_MAX];          // (q/q_i)^-1 mod q_i
+    u64 e_half[TFHE_FAST_MAX];          // floor(q/2) mod q_i
+    u64 rho_q[TFHE_FAST_MAX];
+    u32 sh_q[TFHE_FAST_MAX];
+    barrett_t pb[TFHE_FAST_MAX];        // P moduli
+    u64 e_C[TFHE_FAST_MAX][TFHE_FAST_MAX];  // (q/q_i) mod p_j
+    u64 e_A[TFHE_FAST_MAX];             // q mod p_j
+    u64 e_halfT[TFHE_FAST_MAX];         // floor(q/2) mod p_j
+    // ---- contract ----
+    tw_t c_a1[TFHE_FAST_MAX];           // t (q/q_i)^-1 mod q_i
+    u64 c_b1[TFHE_FAST_MAX];            // h (q/q_i)^-1 mod q_i,  h = (q-1)/2
+    tw_t c_a2[TFHE_FAST_MAX];           // t q^-1 (P/p_j)^-1 mod p_j
+    u64 c_b2[TFHE_FAST_MAX];            // (h q^-1 + floor(P/2)) (P/p_j)^-1 mod p_j
+    u64 c_C1[TFHE_FAST_MAX][TFHE_FAST_MAX];  // (q/q_i) q^-1 (P/p_j)^-1 mod p_j
+    u64 c_A1[TFHE_FAST_MAX];            // q q^-1 (P/p_j)^-1 = (P/p_j)^-1 mod p_j   (times alpha)
+    u64 rho_p[TFHE_FAST_MAX];
+    u32 sh_p[TFHE_FAST_MAX];
+    barrett_t qb[TFHE_FAST_MAX];        // ℛ moduli
+    u64 c_C2[TFHE_FAST_MAX][TFHE_FAST_MAX];  // (P/p_j) mod q_i
+    u64 c_A2[TFHE_FAST_MAX];            // P mod q_i
+    u64 c_halfT[TFHE_FAST_MAX];         // floor(P/2) mod q_i
+    int lazy_q, lazy_p;                 // products that may be accumulated before a reduction (sources q / P)
+    // exact-alpha tables (word arrays in global memory)
+    const u64 *Mq, *Aq, *Mp, *Ap;
+    int nwq, nwp;
+};
+
+template <int K>
+TFHE_HD u64 mac_reduce(const u64 (&xi)[K], const u64* col, int stride, const barrett_t& bt, int lazy) {
+    acc128 acc{0, 0};
+    u64 sum = 0;
+    int pending = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        acc_mac(acc, xi[j], col[(size_t)j * stride]);
+        if (++pending == lazy) {
+            sum = addmod(sum, barrett_reduce128(acc.lo, acc.hi, bt), bt.q);
+            acc = acc128{0, 0};
+            pending = 0;
+        }
+    }
+    if (pending) sum = addmod(sum, barrett_reduce128(acc.lo, acc.hi, bt), bt.q);
+    return sum;
+}
+
+// src: ℛ limb i of this coefficient at src[i*ls]; dst: ℛbig limb l at dst[l*ld]
+template <int NS, int NP>
+TFHE_HD void bfv_expand_fast(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
+    u64 x[NS], xi[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        x[i] = src[(size_t)i * ls];
+        xi[i] = shoup_full(addmod(x[i], B.e_half[i], B.q[i]), B.e_inv[i], B.q[i]);
+    }
+    u64 frac;
+    u32 alpha = conv_alpha_fast<NS>(xi, B.rho_q, B.sh_q, frac);
+    if (frac + 2ull * NS < frac) alpha = conv_alpha_exact<NS>(xi, B.Mq, B.Aq, B.nwq, alpha);
+#pragma unroll
+    for (int i = 0; i < NS; i++) dst[(size_t)B.pos_s[i] * ld] = x[i];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const barrett_t& bt = B.pb[j];
+        u64 r = mac_reduce<NS>(xi, &B.e_C[0][j], TFHE_FAST_MAX, bt, B.lazy_q);
+        r = submod(r, mulmod((u64)alpha, B.e_A[j], bt), bt.q);
+        dst[(size_t)B.pos_p[j] * ld] = submod(r, B.e_halfT[j], bt.q);
+    }
+}
+
+template <int NS, int NP>
+TFHE_HD void bfv_contract_fast(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
+    u64 xi[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++)  // ξ_i of r = (t y + h) mod q
+        xi[i] = addmod(shoup_full(src[(size_t)B.pos_s[i] * ls], B.c_a1[i], B.q[i]), B.c_b1[i], B.q[i]);
+    u64 frac;
+    u32 a1 = conv_alpha_fast<NS>(xi, B.rho_q, B.sh_q, frac);
+    if (frac + 2ull * NS < frac) a1 = conv_alpha_exact<NS>(xi, B.Mq, B.Aq, B.nwq, a1);
+    u64 xp[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {  // ξ'_j of w + floor(P/2) in basis P
+        const barrett_t& bt = B.pb[j];
+        u64 v = addmod(shoup_full(src[(size_t)B.pos_p[j] * ls], B.c_a2[j], bt.q), B.c_b2[j], bt.q);
+        v = submod(v, mac_reduce<NS>(xi, &B.c_C1[0][j], TFHE_FAST_MAX, bt, B.lazy_q), bt.q);
+        xp[j] = addmod(v, mulmod((u64)a1, B.c_A1[j], bt), bt.q);
+    }
+    u32 a2 = conv_alpha_fast<NP>(xp, B.rho_p, B.sh_p, frac);
+    if (frac + 2ull * NP < frac) a2 = conv_alpha_exact<NP>(xp, B.Mp, B.Ap, B.nwp, a2);
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        const barrett_t& bt = B.qb[i];
+        u64 r = mac_reduce<NP>(xp, &B.c_C2[0][i], TFHE_FAST_MAX, bt, B.lazy_p);
+        r = submod(r, mulmod((u64)a2, B.c_A2[i], bt), bt.q);
+        dst[(size_t)i * ld] = submod(r, B.c_halfT[i], bt.q);
+    }
+}

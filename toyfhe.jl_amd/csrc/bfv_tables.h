@@ -107,3 +107,94 @@ inline int build_bfv_host(const std::vector<u64>& qs, const std::vector<u64>& pb
     B.C2 = H->C2.tab;
     return 0;
 }
+
+// ---- folded tables of the register-resident fast path (bfv_fast.h), superset mode only ----
+#include "bfv_fast.h"
+struct bfv_fast_host_t {
+    bfv_fast_tab_t tab;
+    std::vector<u64> Mq, Aq, Mp, Ap;
+};
+// returns false when the configuration is outside the fast path (then the general kernels are used)
+inline bool build_bfv_fast_host(const std::vector<u64>& qs, const std::vector<u64>& pb, u64 t, bfv_fast_host_t* H) {
+    using namespace hostmath;
+    const int ns = (int)qs.size(), nb = (int)pb.size();
+    bfv_fast_tab_t& B = H->tab;
+    memset(&B, 0, sizeof B);
+    std::vector<int> pos_s(ns, -1), pos_p;
+    for (int i = 0; i < ns; i++)
+        for (int j = 0; j < nb; j++)
+            if (pb[j] == qs[i]) pos_s[i] = j;
+    for (int i = 0; i < ns; i++)
+        if (pos_s[i] < 0) return false;
+    std::vector<u64> P;
+    for (int j = 0; j < nb; j++) {
+        bool shared = false;
+        for (int i = 0; i < ns; i++) shared |= (pos_s[i] == j);
+        if (!shared) { pos_p.push_back(j); P.push_back(pb[j]); }
+    }
+    const int np = (int)P.size();
+    if (np < 1 || ns > TFHE_FAST_MAX || np > TFHE_FAST_MAX) return false;
+    B.ns = ns; B.np = np; B.nb = nb;
+    bigint q = big_from(1), Pb = big_from(1);
+    for (u64 x : qs) q = big_mul_u64(q, x);
+    for (u64 x : P) Pb = big_mul_u64(Pb, x);
+    const bigint hq = big_shr1(q), hP = big_shr1(Pb);  // (q-1)/2 = floor(q/2), floor(P/2)
+    std::vector<bigint> Qi(ns), Pj(np);
+    for (int i = 0; i < ns; i++) { Qi[i] = big_from(1); for (int l = 0; l < ns; l++) if (l != i) Qi[i] = big_mul_u64(Qi[i], qs[l]); }
+    for (int j = 0; j < np; j++) { Pj[j] = big_from(1); for (int l = 0; l < np; l++) if (l != j) Pj[j] = big_mul_u64(Pj[j], P[l]); }
+    int maxq = 0, maxp = 0;
+    for (int i = 0; i < ns; i++) {
+        const u64 qi = qs[i];
+        B.pos_s[i] = pos_s[i];
+        B.q[i] = qi;
+        B.qb[i] = make_barrett(qi);
+        const u64 inv = invmod_prime(big_mod_u64(Qi[i], qi), qi);
+        B.e_inv[i] = make_tw(inv, qi);
+        B.e_half[i] = big_mod_u64(hq, qi);
+        const int sh = __builtin_clzll(qi);
+        B.sh_q[i] = (u32)sh;
+        B.rho_q[i] = (u64)((~(u128)0) / ((u128)(qi << sh)) - (((u128)1) << 64));
+        B.c_a1[i] = make_tw(mulmod_slow(t % qi, inv, qi), qi);
+        B.c_b1[i] = mulmod_slow(big_mod_u64(hq, qi), inv, qi);
+        B.c_A2[i] = big_mod_u64(Pb, qi);
+        B.c_halfT[i] = big_mod_u64(hP, qi);
+        maxq = std::max(maxq, bitlen(qi));
+    }
+    for (int j = 0; j < np; j++) {
+        const u64 pj = P[j];
+        B.pos_p[j] = pos_p[j];
+        B.pb[j] = make_barrett(pj);
+        const u64 qinv = invmod_prime(big_mod_u64(q, pj), pj);
+        const u64 invP = invmod_prime(big_mod_u64(Pj[j], pj), pj);
+        const u64 f = mulmod_slow(qinv, invP, pj);
+        B.e_A[j] = big_mod_u64(q, pj);
+        B.e_halfT[j] = big_mod_u64(hq, pj);
+        B.c_a2[j] = make_tw(mulmod_slow(t % pj, f, pj), pj);
+        const u64 hterm = mulmod_slow(big_mod_u64(hq, pj), qinv, pj);
+        B.c_b2[j] = mulmod_slow((hterm + big_mod_u64(hP, pj)) % pj, invP, pj);
+        B.c_A1[j] = invP;
+        const int sh = __builtin_clzll(pj);
+        B.sh_p[j] = (u32)sh;
+        B.rho_p[j] = (u64)((~(u128)0) / ((u128)(pj << sh)) - (((u128)1) << 64));
+        maxp = std::max(maxp, bitlen(pj));
+        for (int i = 0; i < ns; i++) {
+            const u64 c = big_mod_u64(Qi[i], pj);
+            B.e_C[i][j] = c;
+            B.c_C1[i][j] = mulmod_slow(c, f, pj);
+            B.c_C2[j][i] = big_mod_u64(Pj[j], qs[i]);
+        }
+    }
+    auto lazy_of = [](int bits, int k) { const int room = 62 - bits; return std::max(1, std::min(k, room >= 20 ? (1 << 20) : (1 << std::max(0, room)))); };
+    B.lazy_q = lazy_of(maxq, ns);
+    B.lazy_p = lazy_of(maxp, np);
+    B.nwq = (int)q.size();
+    B.nwp = (int)Pb.size();
+    H->Mq.assign((size_t)ns * B.nwq, 0);
+    H->Mp.assign((size_t)np * B.nwp, 0);
+    for (int i = 0; i < ns; i++) for (size_t w = 0; w < Qi[i].size(); w++) H->Mq[(size_t)i * B.nwq + w] = Qi[i][w];
+    for (int j = 0; j < np; j++) for (size_t w = 0; w < Pj[j].size(); w++) H->Mp[(size_t)j * B.nwp + w] = Pj[j][w];
+    H->Aq.assign(q.begin(), q.end());
+    H->Ap.assign(Pb.begin(), Pb.end());
+    B.Mq = H->Mq.data(); B.Aq = H->Aq.data(); B.Mp = H->Mp.data(); B.Ap = H->Ap.data();
+    return true;
+}

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bfv_core.h"
+#include "bfv_fast.h"
 #include "ntt_core.h"
 
 struct limb_sel_t {  // which context modulus each buffer limb uses (crtselect, src/crt.jl:185-211)
@@ -323,4 +324,22 @@ __global__ __launch_bounds__(BFV_BS) void k_bfv_contract(const u64* __restrict__
     u64* zb = xi + (size_t)B.nb * BFV_BS;
     u64* rb = zb + (size_t)B.nb * BFV_BS;
     bfv_contract_coeff(B, src + p * B.nb * n + k, n, dst + p * B.ns * n + k, n, xi, zb, rb, BFV_BS);
+}
+
+// register-resident fast path (bfv_fast.h): ℛbig = ℛ ∪ P with compile-time limb counts
+template <int NS, int NP>
+__global__ __launch_bounds__(256) void k_bfv_expand_fast(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                          const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx) {
+    const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
+    const size_t p = blockIdx.x / gx;
+    if (k >= n) return;
+    bfv_expand_fast<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n);
+}
+template <int NS, int NP>
+__global__ __launch_bounds__(256) void k_bfv_contract_fast(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                            const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx) {
+    const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
+    const size_t p = blockIdx.x / gx;
+    if (k >= n) return;
+    bfv_contract_fast<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
 }

@@ -85,6 +85,7 @@ def lib():
         "tfhe_bfv_plan_create": [vp, i32p, i32, vp, i32p, i32, u64, C.POINTER(vp)],
         "tfhe_bfv_plan_destroy": [vp],
         "tfhe_bfv_plan_set_chunk": [vp, i32],
+        "tfhe_bfv_plan_set_variant": [vp, i32],
         "tfhe_bfv_mul": [vp, vp, vp, vp, i64],
         "tfhe_bfv_expand": [vp, vp, vp, i64],
         "tfhe_bfv_contract": [vp, vp, vp, i64],
@@ -110,7 +111,7 @@ EXPORTED_SYMBOLS = [
     "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
     "tfhe_mul", "tfhe_mad", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
     "tfhe_keyswitch", "tfhe_rotate", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
-    "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
+    "tfhe_bfv_plan_set_variant", "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
     "tfhe_event_create", "tfhe_event_destroy", "tfhe_event_record", "tfhe_event_elapsed_ms",
 ]
 
@@ -292,6 +293,9 @@ class BfvPlan:
 
     def set_chunk(self, n):
         check(lib().tfhe_bfv_plan_set_chunk(self.h, int(n)))
+
+    def set_variant(self, v):
+        check(lib().tfhe_bfv_plan_set_variant(self.h, int(v)))
 
     def mul(self, c1, c2, out, batch):
         check(lib().tfhe_bfv_mul(self.h, c1, c2, out, batch))
