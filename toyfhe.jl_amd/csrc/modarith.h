@@ -31,6 +31,22 @@ TFHE_HD u64 mulhi64(u64 a, u64 b) {
 #endif
 }
 
+// full 64 x 64 -> 128 product as four 32 x 32 + 64 multiply-adds (v_mad_u64_u32); the builtin lo/hi pair costs six
+TFHE_HD void mul64_full(u64 a, u64 b, u64& lo, u64& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = (u64)a0 * b0;
+    const u64 t1 = (u64)a1 * b0 + (p00 >> 32);
+    const u64 t2 = (u64)a0 * b1 + (u32)t1;
+    hi = (u64)a1 * b1 + (t1 >> 32) + (t2 >> 32);
+    lo = (t2 << 32) | (u32)p00;
+#else
+    const u128 p = (u128)a * b;
+    lo = (u64)p;
+    hi = (u64)(p >> 64);
+#endif
+}
+
 // x * w mod q for a precomputed (w, wp); x is ANY u64, result in [0, 2q)  (Harvey/Shoup lazy form)
 TFHE_HD u64 shoup_lazy(u64 x, tw_t t, u64 q) { return x * t.w - mulhi64(x, t.wp) * q; }
 // same, fully reduced to [0, q)
@@ -63,7 +79,8 @@ TFHE_HD u64 barrett_reduce128(u64 zlo, u64 zhi, const barrett_t& m) {
 }
 
 TFHE_HD u64 mulmod(u64 a, u64 b, const barrett_t& m) {
-    u64 lo = a * b, hi = mulhi64(a, b);
+    u64 lo, hi;
+    mul64_full(a, b, lo, hi);
     return barrett_reduce128(lo, hi, m);
 }
 
@@ -72,7 +89,8 @@ struct acc128 {
     u64 lo, hi;
 };
 TFHE_HD void acc_mac(acc128& a, u64 x, u64 y) {
-    u64 lo = x * y, hi = mulhi64(x, y);
+    u64 lo, hi;
+    mul64_full(x, y, lo, hi);
     u64 s = a.lo + lo;
     a.hi += hi + (s < lo);
     a.lo = s;

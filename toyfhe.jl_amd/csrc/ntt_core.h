@@ -133,8 +133,9 @@ struct ArithFp {
         double p, pinv;
         const ftwd_t *W, *Winv;
         ftw_t ninv, w1n;
+        u64 q;
     };
-    static TFHE_HD ctx make(const ntt_limb_t& L) { return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.ninv_d, L.w1inv_ninv_d}; }
+    static TFHE_HD ctx make(const ntt_limb_t& L) { return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.ninv_d, L.w1inv_ninv_d, L.q}; }
     // centred representative: keeps |v| <= p/2 at the start of the first pass (range budget of a 5-stage pass)
     static TFHE_HD elem from_global(u64 x, const ctx& c) {
         const double d = fp_from_u64(x);
@@ -173,6 +174,28 @@ struct ArithFp {
     static TFHE_HD u64 out_fwd(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
     static TFHE_HD u64 out_inv_scaled(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
     static TFHE_HD u64 out_inv_lazy(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
+};
+
+// Optional transforms fused into the block kernels' global I/O (key switching, src/rlwe_she.jl:326-344):
+//   lift_t  : forward first pass reads limb i of a polynomial and lifts it, centred, into limb j --
+//             digit i of the RNS decomposition (SignedMod(limb_i) re-reduced mod q_j, rlwe_she.jl:329)
+//   addend  : inverse last pass adds a coefficient-domain polynomial to its result (c + INTT(S))
+struct lift_t {
+    u64 qi, half, qj;
+    barrett_t bj;
+};
+TFHE_HD u64 lift_digit(u64 x, const lift_t& f) {
+    return x > f.half ? negmod(barrett_reduce128(f.qi - x, 0, f.bj), f.qj) : barrett_reduce128(x, 0, f.bj);
+}
+struct ntt_io_t {
+    u32 mode;         // 0 plain (optional row groups), 1 digit-lift source (forward), 2 addend (inverse)
+    u32 gsz;          // rows per group in the item numbering (0: identity mapping)
+    u32 src_gstride;  // rows per group in the source buffer
+    u32 dst_gstride;  // rows per group in the destination buffer
+    u32 level, nw, polys;  // mode 1: item row = (b*level + i)*nw + j, source row = (b*polys + polys-1)*level + i
+    u32 add_rows;     // mode 2: rows w < add_rows of each group have an addend ...
+    u32 add_gstride;  //         ... at addend row g*add_gstride + w
+    const u64* addend;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -221,7 +244,7 @@ TFHE_HD void fwd_load_tw(typename A::tw* tw, const typename A::ctx& C, u32 tid, 
 }
 // raw 64-bit words of the operands (global: residues; LDS: the policy's element bits)
 template <int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST>
-TFHE_HD void fwd_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid) {
+TFHE_HD void fwd_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, const lift_t* lift = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
@@ -232,6 +255,12 @@ TFHE_HD void fwd_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid) {
             const u32 j = base + ((u32)r << G::LO);
             raw[u * G::R + r] = FIRST ? gsrc[j] : lds[lds_phi<LOGB, LOGT>(j)];
         }
+    }
+    if (FIRST && lift) {
+        TFHE_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < G::E; i++) raw[i] = lift_digit(raw[i], *lift);
+        TFHE_SCHED_FENCE();
     }
 }
 // Butterflies of the pass.  Twiddles of stages d < PF come from `twp` (requested ahead by the caller);
@@ -246,7 +275,9 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
         G::template coords<LAST>(tid, u, c0, hi, base);
         typename A::elem* vv = v + u * G::R;
 #pragma unroll
-        for (int r = 0; r < G::R; r++) vv[r] = FIRST ? A::from_global(raw[u * G::R + r], C) : A::from_lds(raw[u * G::R + r]);
+        for (int r = 0; r < G::R; r++) {
+            vv[r] = FIRST ? A::from_global(raw[u * G::R + r], C) : A::from_lds(raw[u * G::R + r]);
+        }
 #pragma unroll
         for (int d = 0; d < K; d++) {
             const int half = 1 << (K - 1 - d);
@@ -290,11 +321,11 @@ TFHE_HD void fwd_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
 }
 template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST>
 TFHE_HD void ntt_fwd_pass(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid, u32 pre, int x,
-                          u32 sb_rev) {
+                          u32 sb_rev, const lift_t* lift = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
     u64 raw[G::E];
     typename A::elem v[G::E];
-    fwd_load_data<LOGB, LOGT, S0, K, FIRST, LAST>(raw, lds, gsrc, tid);
+    fwd_load_data<LOGB, LOGT, S0, K, FIRST, LAST>(raw, lds, gsrc, tid, FIRST ? lift : nullptr);
     fwd_compute<A, LOGB, LOGT, S0, K, FIRST, LAST, 0>(v, raw, nullptr, C, tid, pre);
     fwd_store<A, LOGB, LOGT, S0, K, LAST>(v, lds, gdst, C, tid, x, sb_rev);
 }
@@ -373,9 +404,18 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
     }
 }
 template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE>
-TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename A::ctx& C, u32 tid) {
+TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename A::ctx& C, u32 tid,
+                       const u64* addend = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
     constexpr bool TO_GLOBAL = (S0 == 0);
+    u64 o[TO_GLOBAL ? G::E : 1];
+    if (TO_GLOBAL) {
+        // finish every result before the store phase starts (otherwise the scheduler interleaves the two
+        // and the register allocator spills)
+#pragma unroll
+        for (int i = 0; i < G::E; i++) o[i] = SCALE ? A::out_inv_scaled(v[i], C) : A::out_inv_lazy(v[i], C);
+        TFHE_SCHED_FENCE();
+    }
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
         u32 c0, hi, base;
@@ -383,10 +423,12 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
 #pragma unroll
         for (int r = 0; r < G::R; r++) {
             const u32 j = base + ((u32)r << G::LO);
-            typename A::elem e = v[u * G::R + r];
             if (TO_GLOBAL) {
-                gdst[j] = SCALE ? A::out_inv_scaled(e, C) : A::out_inv_lazy(e, C);
+                u64 w = o[u * G::R + r];
+                if (SCALE && addend) w = addmod(w, addend[j], C.q);
+                gdst[j] = w;
             } else {
+                typename A::elem e = v[u * G::R + r];
                 A::range_inv(e, C);
                 lds[lds_phi<LOGB, LOGT>(j)] = A::to_lds(e);
             }
@@ -395,14 +437,14 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
 }
 template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool TO_GLOBAL, bool SCALE>
 TFHE_HD void ntt_inv_pass(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid, u32 pre, int x,
-                          u32 sb_rev) {
+                          u32 sb_rev, const u64* addend = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
     static_assert(TO_GLOBAL == (S0 == 0), "TO_GLOBAL pass is the one ending at stage 0");
     u64 raw[G::E];
     typename A::elem v[G::E];
     inv_load_data<LOGB, LOGT, S0, K, FROM_GLOBAL>(raw, lds, gsrc, tid, x, sb_rev);
     inv_compute<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE, 0>(v, raw, nullptr, C, tid, pre);
-    inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid);
+    inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid, TO_GLOBAL ? addend : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

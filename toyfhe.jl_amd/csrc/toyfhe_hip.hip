@@ -119,11 +119,16 @@ bool sel_fp(const tfhe_ctx* c, const limb_sel_t& sel, int x) {
     return true;
 }
 
-template <class A, int LOGB>
-int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x) {
+ntt_io_t io_plain() { ntt_io_t io; memset(&io, 0, sizeof io); return io; }
+
+template <class A, int LOGB, int IOMODE = 0>
+int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x, const ntt_io_t& io) {
+    if constexpr (IOMODE == 0) {
+        if (io.mode == 1) return launch_block_fwd<A, LOGB, 1>(c, src, dst, rows, sel, x, io);
+    }
     constexpr int LOGT = logt_for(LOGB);
     const size_t lds = (size_t)lds_words<LOGB, LOGT>() * 8;
-    auto kern = k_ntt_fwd_block<A, LOGB, LOGT>;
+    auto kern = k_ntt_fwd_block<A, LOGB, LOGT, IOMODE>;
     static bool attr_set = false;
     if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
     // persistent workgroups: as many as are co-resident (LDS-limited), each loops over items
@@ -131,16 +136,19 @@ int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const 
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(160 * 1024) / lds, (size_t)2048 >> LOGT}));
     const unsigned grid = std::min(items, (unsigned)c->num_cus * per_cu);
     prof_begin(c, rows);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items, io);
     prof_end(c);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
-template <class A, int LOGB>
-int launch_block_inv(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x) {
+template <class A, int LOGB, int IOMODE = 0>
+int launch_block_inv(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x, const ntt_io_t& io) {
+    if constexpr (IOMODE == 0) {
+        if (io.mode == 2) return launch_block_inv<A, LOGB, 2>(c, src, dst, rows, sel, x, io);
+    }
     constexpr int LOGT = logt_for(LOGB);
     const size_t lds = (size_t)lds_words<LOGB, LOGT>() * 8;
-    auto kern = k_ntt_inv_block<A, LOGB, LOGT>;
+    auto kern = k_ntt_inv_block<A, LOGB, LOGT, IOMODE>;
     static bool attr_set = false;
     if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
     // persistent workgroups: as many as are co-resident (LDS-limited), each loops over items
@@ -148,13 +156,13 @@ int launch_block_inv(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const 
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(160 * 1024) / lds, (size_t)2048 >> LOGT}));
     const unsigned grid = std::min(items, (unsigned)c->num_cus * per_cu);
     prof_begin(c, rows);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items, io);
     prof_end(c);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
 
-int launch_generic(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel) {
+int launch_generic(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, const ntt_io_t& io) {
     const size_t lds = (size_t)c->N * 8;
     static bool attr_set = false;
     if (!attr_set) {
@@ -167,33 +175,36 @@ int launch_generic(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t 
     const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, c->N / 2));
     prof_begin(c, rows);
     if (inverse)
-        hipLaunchKernelGGL(k_ntt_inv_generic, dim3((unsigned)rows), dim3(threads), lds, c->stream, src, dst, c->limbs_dev, sel, c->logN);
+        hipLaunchKernelGGL(k_ntt_inv_generic, dim3((unsigned)rows), dim3(threads), lds, c->stream, src, dst, c->limbs_dev, sel, c->logN, io);
     else
-        hipLaunchKernelGGL(k_ntt_fwd_generic, dim3((unsigned)rows), dim3(threads), lds, c->stream, src, dst, c->limbs_dev, sel, c->logN);
+        hipLaunchKernelGGL(k_ntt_fwd_generic, dim3((unsigned)rows), dim3(threads), lds, c->stream, src, dst, c->limbs_dev, sel, c->logN, io);
     prof_end(c);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
 
 // forward / inverse transform of `rows` limb-polynomials; src == dst allowed
-int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel) {
+// `io` (optional) selects the fused global-I/O transforms of ntt_io_t; only for N <= 2^14 (single-block transforms)
+int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, const ntt_io_t* iop = nullptr) {
     if (rows == 0) return TFHE_OK;
+    const ntt_io_t io = iop ? *iop : io_plain();
     if (rows < 0 || (rows << std::max(0, c->logN - 14)) > 0x7fffffffll) return fail(TFHE_E_BADARG, "bad polynomial count");
     const int n = c->logN;
     const bool use_block = (c->variant != 1 && n >= 10) || n > 14;
-    if (!use_block) return launch_generic(c, inverse, src, dst, rows, sel);
+    if (!use_block) return launch_generic(c, inverse, src, dst, rows, sel, io);
     if (n <= 14) {
         const bool fp = sel_fp(c, sel, 0);
         switch (n) {
 #define CASE_(LB)                                                                                                  \
     case LB:                                                                                                       \
-        if (fp) return inverse ? launch_block_inv<ArithFp, LB>(c, src, dst, rows, sel, 0) : launch_block_fwd<ArithFp, LB>(c, src, dst, rows, sel, 0); \
-        return inverse ? launch_block_inv<ArithInt, LB>(c, src, dst, rows, sel, 0) : launch_block_fwd<ArithInt, LB>(c, src, dst, rows, sel, 0);
+        if (fp) return inverse ? launch_block_inv<ArithFp, LB>(c, src, dst, rows, sel, 0, io) : launch_block_fwd<ArithFp, LB>(c, src, dst, rows, sel, 0, io); \
+        return inverse ? launch_block_inv<ArithInt, LB>(c, src, dst, rows, sel, 0, io) : launch_block_fwd<ArithInt, LB>(c, src, dst, rows, sel, 0, io);
             CASE_(10) CASE_(11) CASE_(12) CASE_(13) CASE_(14)
 #undef CASE_
         }
     }
     // N > 2^14: x top stages on global memory + 2^14 blocks; needs an out-of-place intermediate
+    if (iop) return fail(TFHE_E_UNSUPPORTED, "fused NTT I/O transforms need N <= 2^14");
     const int x = n - 14;
     if (x > 3) return fail(TFHE_E_UNSUPPORTED, "N = 2^%d not supported (max 2^17)", n);
     void* tmp = nullptr;
@@ -210,9 +221,9 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
         }
         prof_end(c);
         HIP_TRY(hipGetLastError());
-        return launch_block_fwd<ArithInt, 14>(c, t, dst, rows, sel, x);
+        return launch_block_fwd<ArithInt, 14>(c, t, dst, rows, sel, x, io);
     }
-    rc = launch_block_inv<ArithInt, 14>(c, src, t, rows, sel, x);
+    rc = launch_block_inv<ArithInt, 14>(c, src, t, rows, sel, x, io);
     if (rc) return rc;
     prof_begin(c, 0);
     switch (x) {
@@ -484,8 +495,12 @@ int tfhe_galois(tfhe_ctx* c, const uint64_t* src, uint64_t* dst, uint64_t g, int
 }
 
 // ---- keyswitch ------------------------------------------------------------------------------------
+// One chunk of key switching (rlwe_she.jl:315-347).  By linearity of the NTT the expanded inputs never need
+// transforming:  out_s = c_s + INTT(S_s)  (plain)   or   c_s + modswitch-part of INTT(S_s)  (ModulusRaised),
+// with S_s = Σ_i evk_{i,s} ⊙ NTT(digit_i)  (see k_ks_inner, k_ks_rescale_add).
+//   dig: [batch][level][nw][N]  NTT'd digits      S: [batch][2][nw][N]
 static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
-                    u64* acc, u64* dig) {
+                    u64* S, u64* dig) {
     const int nw = special ? level + 1 : level;
     ks_arg_t A;
     memset(&A, 0, sizeof A);
@@ -493,24 +508,46 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
     A.w.n = nw;
     for (int j = 0; j < level; j++) A.w.idx[j] = j;
     if (special) A.w.idx[level] = Lk - 1;  // downswitch_keyelement, modulusraising.jl:43-49
-    const u64 P = c->q[Lk - 1];
-    for (int j = 0; j < level; j++) A.pmul[j] = hostmath::make_tw(special ? P % c->q[j] : 1, c->q[j]);
     const u32 n = (u32)c->N;
-    hipLaunchKernelGGL(k_ks_init, dim3((unsigned)(batch * 2 * nw)), dim3(256), 0, c->stream, ct, acc, c->limbs_dev, A, n);
-    hipLaunchKernelGGL(k_ks_digits, dim3((unsigned)(batch * level * nw)), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n);
-    HIP_TRY(hipGetLastError());
-    int rc = run_ntt(c, false, acc, acc, batch * 2 * nw, A.w);
-    if (rc) return rc;
-    rc = run_ntt(c, false, dig, dig, batch * level * nw, A.w);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_ks_inner, dim3((unsigned)(batch * nw)), dim3(256), 0, c->stream, evk, dig, acc, c->limbs_dev, A, Lk, n);
+    const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
+    int rc;
+    if (c->logN <= 14) {
+        // digits: centred lift of limb i of c[end] into every working limb, fused into the forward NTT's loads
+        ntt_io_t io = io_plain();
+        io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys;
+        rc = run_ntt(c, false, ct, dig, batch * level * nw, A.w, &io);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k_ks_digits, dim3((unsigned)(batch * level * nw)), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n);
+        HIP_TRY(hipGetLastError());
+        rc = run_ntt(c, false, dig, dig, batch * level * nw, A.w);
+        if (rc) return rc;
+    }
+    const unsigned gx = (n + 255) / 256;
+    hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch);
     HIP_TRY(hipGetLastError());
     if (special) {
-        rc = run_ntt(c, true, acc, acc, batch * 2 * nw, A.w);
+        rc = run_ntt(c, true, S, S, batch * 2 * nw, A.w);
         if (rc) return rc;
-        return do_rescale(c, acc, out, batch * 2, A.w);  // keyswitch_contract = modswitch, modulusraising.jl:42
+        rescale_arg_t ra;
+        memset(&ra, 0, sizeof ra);
+        const u64 P = c->q[Lk - 1];
+        for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+        hipLaunchKernelGGL(k_ks_rescale_add, dim3((unsigned)(batch * 2 * level)), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
     }
-    return run_ntt(c, true, acc, out, batch * 2 * nw, A.w);
+    if (c->logN <= 14) {  // out = c + INTT(S), the addition fused into the inverse NTT's stores
+        ntt_io_t io = io_plain();
+        io.mode = 2; io.gsz = (u32)(2 * level); io.src_gstride = io.gsz; io.dst_gstride = io.gsz;
+        io.add_rows = add_s * (u32)level; io.add_gstride = (u32)(polys * level); io.addend = ct;
+        return run_ntt(c, true, S, out, batch * 2 * nw, A.w, &io);
+    }
+    rc = run_ntt(c, true, S, out, batch * 2 * nw, A.w);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ks_add_ct, dim3((unsigned)(batch * 2 * level)), dim3(256), 0, c->stream, ct, out, c->limbs_dev, A, n, add_s);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
 }
 
 static int ks_check(tfhe_ctx* c, int Lk, int level, int special, const void* evk, int n_digits, const void* ct, int polys, const void* out, int64_t batch) {
