@@ -132,7 +132,7 @@ int tfhe_bfv_mul_relin(tfhe_bfv_plan *plan, const uint64_t *evk, int n_digits, c
 /* expand/contract kernel family: 0 = auto (register-resident constant-folded kernels when ℛbig ⊇ ℛ and the
  * limb counts are instantiated, else the general kernels), 1 = force the general kernels (cross-check). */
 int tfhe_bfv_plan_set_variant(tfhe_bfv_plan *plan, int variant);
-/* ciphertexts processed per internal chunk (workspace = chunk * 7 * nb * N * 8 bytes); 0 = default */
+/* ciphertexts processed per internal chunk (workspace = chunk * (7 nb + 3 ns) * N * 8 bytes); 0 = default (128) */
 int tfhe_bfv_plan_set_chunk(tfhe_bfv_plan *plan, int chunk);
 
 /* ---- measurement hooks (bench.py): HIP events on the ctx stream --------------------------------

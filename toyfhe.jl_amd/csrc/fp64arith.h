@@ -14,7 +14,7 @@
 // Range bookkeeping (in units of p, a = p 2^-52 <= 0.28125, growth per forward stage b' = b (1 + 1.5 a) + 1/2):
 //   forward, from |v| <= 1/2 (LDS values are reduced, global inputs are centred):
 //        1.21, 2.22, 3.66, 5.70 after 1..4 stages  < 2^53 / p >= 7.1;  5-stage passes reduce after stage 3
-//   inverse, reduce after every second stage: sums double (1/2 -> 2), products stay <= 1.4
+//   inverse, reduce after every third stage: sums double (1/2 -> 4), products stay <= 1/2 + 1.5 a 4 = 2.2
 #pragma once
 #include "modarith.h"
 

@@ -295,8 +295,11 @@ struct ks_arg_t {
 template <int DCH>
 __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, const u64* __restrict__ dig,
                                                    u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
-                                                   int Lk, u32 n, u32 batch) {
-    const u32 gx = (n + 255) / 256, j = blockIdx.x / gx, k = (blockIdx.x % gx) * 256 + threadIdx.x;
+                                                   int Lk, u32 n, u32 batch, u32 bsplit) {
+    // blockIdx.x = (slice * nw + j) * gx + tile; slice = which part of the batch this workgroup owns
+    const u32 gx = (n + 255) / 256, tile = blockIdx.x % gx, j = (blockIdx.x / gx) % (u32)A.nw, slice = blockIdx.x / (gx * (u32)A.nw);
+    const u32 k = tile * 256 + threadIdx.x;
+    const u32 per = (batch + bsplit - 1) / bsplit, b_lo = slice * per, b_hi = b_lo + per < batch ? b_lo + per : batch;
     if (k >= n) return;
     const ntt_limb_t L = LT[A.w.idx[j]];
     const int lazy = L.br.sh <= 50 ? (1 << 10) : (L.br.sh <= 58 ? (1 << (60 - L.br.sh)) : 1);
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
             mk[ii] = evk[(((size_t)i * 2 + 0) * Lk + A.w.idx[j]) * n + k];
             md[ii] = evk[(((size_t)i * 2 + 1) * Lk + A.w.idx[j]) * n + k];
         }
-        for (u32 b = 0; b < batch; b++) {
+        for (u32 b = b_lo; b < b_hi; b++) {
             u64* s1p = S + (((size_t)b * 2 + 0) * A.nw + j) * n + k;
             u64* s2p = S + (((size_t)b * 2 + 1) * A.nw + j) * n + k;
             acc128 s1{0, 0}, s2{0, 0};

@@ -91,6 +91,15 @@ struct ntt_limb_t {   // per-limb constants (device copy lives in the context)
     const ftwd_t* Winvd;
 };
 
+// digit lift of the RNS key-switch decomposition (see ntt_io_t below)
+struct lift_t {
+    u64 qi, half, qj;
+    barrett_t bj;
+};
+TFHE_HD u64 lift_digit(u64 x, const lift_t& f) {
+    return x > f.half ? negmod(barrett_reduce128(f.qi - x, 0, f.bj), f.qj) : barrett_reduce128(x, 0, f.bj);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Arithmetic policies for the block passes: the index logic is shared, the element type and the
 // butterfly differ.  ArithInt: u64 Harvey/Shoup (any q < 2^62).  ArithFp: exact integers in doubles
@@ -107,6 +116,7 @@ struct ArithInt {
     };
     static TFHE_HD ctx make(const ntt_limb_t& L) { return ctx{L.q, L.W, L.Winv, L.ninv, L.w1inv_ninv}; }
     static TFHE_HD elem from_global(u64 x, const ctx&) { return x; }
+    static TFHE_HD elem from_global_lift(u64 x, const ctx&, const lift_t& f) { return lift_digit(x, f); }
     static TFHE_HD elem from_lds(u64 x) { return x; }
     static TFHE_HD u64 to_lds(elem v) { return v; }
     static TFHE_HD tw ld_fwd(const ctx& c, u32 i) { return ld_tw(c.W, i); }
@@ -140,6 +150,12 @@ struct ArithFp {
     static TFHE_HD elem from_global(u64 x, const ctx& c) {
         const double d = fp_from_u64(x);
         return d + d > c.p ? d - c.p : d;
+    }
+    // digit lift in fp64: centred residue of limb i (|d| <= q_i/2 < 2^51, exact) reduced mod p_j
+    static TFHE_HD elem from_global_lift(u64 x, const ctx& c, const lift_t& f) {
+        double d = fp_from_u64(x);
+        d = x > f.half ? d - (double)f.qi : d;
+        return fp_reduce(d, c.p, c.pinv);
     }
     static TFHE_HD elem from_lds(u64 x) { double d; __builtin_memcpy(&d, &x, 8); return d; }
     static TFHE_HD u64 to_lds(elem v) { u64 b; __builtin_memcpy(&b, &v, 8); return b; }
@@ -180,13 +196,6 @@ struct ArithFp {
 //   lift_t  : forward first pass reads limb i of a polynomial and lifts it, centred, into limb j --
 //             digit i of the RNS decomposition (SignedMod(limb_i) re-reduced mod q_j, rlwe_she.jl:329)
 //   addend  : inverse last pass adds a coefficient-domain polynomial to its result (c + INTT(S))
-struct lift_t {
-    u64 qi, half, qj;
-    barrett_t bj;
-};
-TFHE_HD u64 lift_digit(u64 x, const lift_t& f) {
-    return x > f.half ? negmod(barrett_reduce128(f.qi - x, 0, f.bj), f.qj) : barrett_reduce128(x, 0, f.bj);
-}
 struct ntt_io_t {
     u32 mode;         // 0 plain (optional row groups), 1 digit-lift source (forward), 2 addend (inverse)
     u32 gsz;          // rows per group in the item numbering (0: identity mapping)
@@ -256,19 +265,19 @@ TFHE_HD void fwd_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, c
             raw[u * G::R + r] = FIRST ? gsrc[j] : lds[lds_phi<LOGB, LOGT>(j)];
         }
     }
-    if (FIRST && lift) {
-        TFHE_SCHED_FENCE();
-#pragma unroll
-        for (int i = 0; i < G::E; i++) raw[i] = lift_digit(raw[i], *lift);
-        TFHE_SCHED_FENCE();
-    }
+    (void)lift;
 }
 // Butterflies of the pass.  Twiddles of stages d < PF come from `twp` (requested ahead by the caller);
 // the others are loaded here (the compiler schedules those loads).
 template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int PF>
 TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
-                         u32 pre) {
+                         u32 pre, const lift_t* lift = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
+    if (FIRST && lift) {  // digit lift: all conversions first, then the butterflies (register pressure)
+#pragma unroll
+        for (int i = 0; i < G::E; i++) v[i] = A::from_global_lift(raw[i], C, *lift);
+        TFHE_SCHED_FENCE();
+    }
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
         u32 c0, hi, base;
@@ -276,6 +285,7 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
         typename A::elem* vv = v + u * G::R;
 #pragma unroll
         for (int r = 0; r < G::R; r++) {
+            if (FIRST && lift) continue;
             vv[r] = FIRST ? A::from_global(raw[u * G::R + r], C) : A::from_lds(raw[u * G::R + r]);
         }
 #pragma unroll
@@ -325,8 +335,8 @@ TFHE_HD void ntt_fwd_pass(u64* lds, const u64* gsrc, u64* gdst, const typename A
     typedef pgeom<LOGB, LOGT, S0, K> G;
     u64 raw[G::E];
     typename A::elem v[G::E];
-    fwd_load_data<LOGB, LOGT, S0, K, FIRST, LAST>(raw, lds, gsrc, tid, FIRST ? lift : nullptr);
-    fwd_compute<A, LOGB, LOGT, S0, K, FIRST, LAST, 0>(v, raw, nullptr, C, tid, pre);
+    fwd_load_data<LOGB, LOGT, S0, K, FIRST, LAST>(raw, lds, gsrc, tid);
+    fwd_compute<A, LOGB, LOGT, S0, K, FIRST, LAST, 0>(v, raw, nullptr, C, tid, pre, FIRST ? lift : nullptr);
     fwd_store<A, LOGB, LOGT, S0, K, LAST>(v, lds, gdst, C, tid, x, sb_rev);
 }
 
@@ -395,8 +405,9 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
                     }
                 }
             }
-            // range control after every second processed stage (pass ends are handled by the store)
-            if (((K - 1 - d) & 1) == 1 && d != 0) {
+            // range control after every third processed stage (pass ends are handled by the store): sums double per
+            // stage, 1/2 -> 4 over three stages, products stay <= 2.2 (fp64arith.h)
+            if (((K - 1 - d) % 3) == 2 && d != 0) {
 #pragma unroll
                 for (int r = 0; r < G::R; r++) A::range_inv(vv[r], C);
             }

@@ -524,7 +524,9 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         if (rc) return rc;
     }
     const unsigned gx = (n + 255) / 256;
-    hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch);
+    // enough workgroups to fill the chip: split the batch into slices (the key is re-read once per slice)
+    const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx - 1) / (nw * gx)));
+    hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit);
     HIP_TRY(hipGetLastError());
     if (special) {
         rc = run_ntt(c, true, S, S, batch * 2 * nw, A.w);
@@ -567,7 +569,7 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
     const size_t N = (size_t)c->N;
     // chunk the batch so that the digit tensor stays at a few hundred MiB
     const size_t per_ct = ((size_t)2 * nw + (size_t)level * nw + (rotate ? (size_t)polys * level : 0)) * N * 8;
-    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(batch, (int64_t)((512ull << 20) / per_ct)));
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)128, (int64_t)((2048ull << 20) / per_ct)}));
     void* ws = nullptr;
     // NTT of N > 2^14 uses the context workspace as well: keep ours separate by over-allocating
     const size_t ntt_tmp = c->logN > 14 ? (size_t)chunk * std::max(2, level) * nw * N * 8 : 0;
