@@ -83,10 +83,9 @@ extern "C" {
 int emul_ntt(int logn, uint64_t q, uint64_t psi, int inverse, int variant, const uint64_t* src, uint64_t* dst) {
     const int64_t N = 1ll << logn;
     if (!psi) psi = hostmath::minimal_primitive_root(q, 2 * (u64)N);
-    std::vector<twd_t> W, Wi;
-    std::vector<ftwd_t> Wd, Wid;
+    ntt_host_tabs_t HT;
     ntt_limb_t L;
-    if (build_ntt_tables(N, q, psi, W, Wi, &L, &Wd, &Wid)) return -1;
+    if (build_ntt_tables_all(N, q, psi, HT, &L)) return -1;
     g_force_int = (variant == 2);
     if (variant == 1 || logn < 10) {
         if (logn > 14) return -2;

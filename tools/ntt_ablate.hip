@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstring>
 #include "../toyfhe.jl_amd/csrc/kernels.h"
 #include "../toyfhe.jl_amd/csrc/ntt_tables.h"
 
@@ -12,16 +13,17 @@ template <class A>
 void run(const char* name, const ntt_limb_t* LT, int L, u64* d_a, u64* d_b, int rows, bool inverse) {
     limb_sel_t sel; sel.n = L; for (int j = 0; j < L; j++) sel.idx[j] = j;
     const size_t lds = (size_t)lds_words<14, logt_for(14)>() * 8;
-    auto kf = k_ntt_fwd_block<A, 14, logt_for(14)>; auto ki = k_ntt_inv_block<A, 14, logt_for(14)>;
+    auto kf = k_ntt_fwd_block<A, 14, logt_for(14), 0>; auto ki = k_ntt_inv_block<A, 14, logt_for(14), 0>;
     hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int grid = rows < 256 ? rows : 256;
+    ntt_io_t io; memset(&io, 0, sizeof io);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(e0);
         for (int it = 0; it < 5; it++) {
-            if (inverse) hipLaunchKernelGGL(ki, dim3(grid), dim3(1 << logt_for(14)), lds, 0, d_a, d_b, LT, sel, 0, (u32)rows);
-            else hipLaunchKernelGGL(kf, dim3(grid), dim3(1 << logt_for(14)), lds, 0, d_a, d_b, LT, sel, 0, (u32)rows);
+            if (inverse) hipLaunchKernelGGL(ki, dim3(grid), dim3(1 << logt_for(14)), lds, 0, d_a, d_b, LT, sel, 0, (u32)rows, io);
+            else hipLaunchKernelGGL(kf, dim3(grid), dim3(1 << logt_for(14)), lds, 0, d_a, d_b, LT, sel, 0, (u32)rows, io);
         }
         hipEventRecord(e1); hipEventSynchronize(e1);
     }
@@ -37,13 +39,13 @@ int main(int argc, char** argv) {
     u64 q = (1ull << 50) + 1;
     for (int l = 0; l < L; l++) {
         do { q += 2 * N; } while (!hostmath::is_prime(q));
-        std::vector<twd_t> W, Wi; std::vector<ftwd_t> Wd, Wid;
-        build_ntt_tables(N, q, hostmath::minimal_primitive_root(q, 2 * N), W, Wi, &LT[l], &Wd, &Wid);
-        twd_t *a, *b; ftwd_t *c, *d;
-        hipMalloc(&a, N * 16); hipMalloc(&b, N * 16); hipMalloc(&c, N * 16); hipMalloc(&d, N * 16);
-        hipMemcpy(a, W.data(), N * 16, hipMemcpyHostToDevice); hipMemcpy(b, Wi.data(), N * 16, hipMemcpyHostToDevice);
-        hipMemcpy(c, Wd.data(), N * 16, hipMemcpyHostToDevice); hipMemcpy(d, Wid.data(), N * 16, hipMemcpyHostToDevice);
-        LT[l].W = a; LT[l].Winv = b; LT[l].Wd = c; LT[l].Winvd = d;
+        ntt_host_tabs_t HT;
+        build_ntt_tables_all(N, q, hostmath::minimal_primitive_root(q, 2 * N), HT, &LT[l]);
+        auto up = [&](const void* h, size_t bytes) { void* d; hipMalloc(&d, bytes); hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); return d; };
+        LT[l].W = (twd_t*)up(HT.W.data(), N * 16); LT[l].Winv = (twd_t*)up(HT.Wi.data(), N * 16);
+        LT[l].Wb = (twd_t*)up(HT.Wb.data(), N * 16); LT[l].Winvb = (twd_t*)up(HT.Wib.data(), N * 16);
+        LT[l].Wd = (ftwd_t*)up(HT.Wd.data(), N * 8); LT[l].Winvd = (ftwd_t*)up(HT.Wid.data(), N * 8);
+        LT[l].Wdb = (ftwd_t*)up(HT.Wdb.data(), N * 8); LT[l].Winvdb = (ftwd_t*)up(HT.Widb.data(), N * 8);
     }
     ntt_limb_t* dLT; hipMalloc(&dLT, L * sizeof(ntt_limb_t)); hipMemcpy(dLT, LT.data(), L * sizeof(ntt_limb_t), hipMemcpyHostToDevice);
     u64 *d_a, *d_b; hipMalloc(&d_a, (size_t)rows * N * 8); hipMalloc(&d_b, (size_t)rows * N * 8);

@@ -89,6 +89,14 @@ struct ntt_limb_t {   // per-limb constants (device copy lives in the context)
     ftw_t ninv_d, w1inv_ninv_d;
     const ftwd_t* Wd;
     const ftwd_t* Winvd;
+    // copies of the tables permuted for the boundary pass (forward last / inverse first pass), whose thread->group
+    // map is bit-reversed: entry (2^s + (c0 << d) + g) of the copy = entry (2^s + (brv(c0) << d) + g) of the
+    // table, so that the lanes of a wavefront read consecutive entries instead of 64 different cache lines.
+    // Valid for whole-transform blocks (x == 0) of the geometry they were built for; nullptr otherwise.
+    const twd_t* Wb;
+    const twd_t* Winvb;
+    const ftwd_t* Wdb;
+    const ftwd_t* Winvdb;
 };
 
 // digit lift of the RNS key-switch decomposition (see ntt_io_t below)
@@ -111,10 +119,13 @@ struct ArithInt {
     typedef tw_t tw;
     struct ctx {
         u64 q;
-        const twd_t *W, *Winv;
+        const twd_t *W, *Winv, *Wb, *Winvb;
         tw_t ninv, w1n;
     };
-    static TFHE_HD ctx make(const ntt_limb_t& L) { return ctx{L.q, L.W, L.Winv, L.ninv, L.w1inv_ninv}; }
+    static TFHE_HD ctx make(const ntt_limb_t& L) { return ctx{L.q, L.W, L.Winv, L.Wb, L.Winvb, L.ninv, L.w1inv_ninv}; }
+    static TFHE_HD tw ld_fwd_b(const ctx& c, u32 i) { return ld_tw(c.Wb, i); }
+    static TFHE_HD tw ld_inv_b(const ctx& c, u32 i) { return ld_tw(c.Winvb, i); }
+    static TFHE_HD bool has_b(const ctx& c) { return c.Wb != nullptr; }
     static TFHE_HD elem from_global(u64 x, const ctx&) { return x; }
     static TFHE_HD elem from_global_lift(u64 x, const ctx&, const lift_t& f) { return lift_digit(x, f); }
     static TFHE_HD elem from_lds(u64 x) { return x; }
@@ -141,11 +152,13 @@ struct ArithFp {
     typedef ftw_t tw;
     struct ctx {
         double p, pinv;
-        const ftwd_t *W, *Winv;
+        const ftwd_t *W, *Winv, *Wb, *Winvb;
         ftw_t ninv, w1n;
         u64 q;
     };
-    static TFHE_HD ctx make(const ntt_limb_t& L) { return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.ninv_d, L.w1inv_ninv_d, L.q}; }
+    static TFHE_HD ctx make(const ntt_limb_t& L) {
+        return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.Wdb, L.Winvdb, L.ninv_d, L.w1inv_ninv_d, L.q};
+    }
     // centred representative: keeps |v| <= p/2 at the start of the first pass (range budget of a 5-stage pass)
     static TFHE_HD elem from_global(u64 x, const ctx& c) {
         const double d = fp_from_u64(x);
@@ -170,6 +183,9 @@ struct ArithFp {
     }
     static TFHE_HD tw ld_fwd(const ctx& c, u32 i) { return ld(c.W, i); }
     static TFHE_HD tw ld_inv(const ctx& c, u32 i) { return ld(c.Winv, i); }
+    static TFHE_HD tw ld_fwd_b(const ctx& c, u32 i) { return ld(c.Wb, i); }
+    static TFHE_HD tw ld_inv_b(const ctx& c, u32 i) { return ld(c.Winvb, i); }
+    static TFHE_HD bool has_b(const ctx& c) { return c.Wb != nullptr; }
     static TFHE_HD void bf_fwd(elem& x, elem& y, tw w, const ctx& c) {
         const double t = fp_mulmod_c(y, w, c.p, c.pinv);
         y = x - t;
@@ -273,6 +289,7 @@ template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int
 TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
                          u32 pre, const lift_t* lift = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
+    const bool use_b = LAST && pre == 1u && A::has_b(C);  // permuted boundary table (whole-transform blocks only)
     if (FIRST && lift) {  // digit lift: all conversions first, then the butterflies (register pressure)
 #pragma unroll
         for (int i = 0; i < G::E; i++) v[i] = A::from_global_lift(raw[i], C, *lift);
@@ -294,7 +311,8 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
 #pragma unroll
             for (int g = 0; g < (1 << d); g++) {
                 const typename A::tw w = d < PF ? twp[u * G::NTW + (1 << d) - 1 + g]
-                                                : A::ld_fwd(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
+                                         : (LAST && use_b) ? A::ld_fwd_b(C, (1u << (S0 + d)) + (c0 << d) + (u32)g)
+                                                           : A::ld_fwd(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
 #pragma unroll
                 for (int i = 0; i < half; i++) {
                     const int r0 = (g << (K - d)) + i;
@@ -379,6 +397,7 @@ template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCA
 TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
                          u32 pre) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
+    const bool use_b = FROM_GLOBAL && pre == 1u && A::has_b(C);
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
         u32 c0, hi, base;
@@ -397,7 +416,8 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
                     for (int i = 0; i < half; i++) A::bf_inv_scaled(vv[i], vv[i + half], C);
                 } else {
                     const typename A::tw w = d >= K - PF ? twp[u * G::NTW + (1 << d) - 1 + g]
-                                                         : A::ld_inv(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
+                                             : (FROM_GLOBAL && use_b) ? A::ld_inv_b(C, (1u << (S0 + d)) + (c0 << d) + (u32)g)
+                                                                      : A::ld_inv(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
 #pragma unroll
                     for (int i = 0; i < half; i++) {
                         const int r0 = (g << (K - d)) + i;

@@ -8,6 +8,27 @@
 #include "ntt_core.h"
 
 // returns 0, or -1 if psi is not a primitive 2N-th root of unity mod q
+// permutation of the boundary-pass stages (see ntt_limb_t::Wb): for stage s >= logN - Kb, d = s - (logN - Kb),
+// position (2^s + (c0 << d) + g) holds entry (2^s + (brv_{logN-Kb}(c0) << d) + g)
+template <class T>
+inline void permute_boundary(const std::vector<T>& in, std::vector<T>& out, int logN, int Kb) {
+    out = in;
+    const int hb = logN - Kb;  // bits of the group index
+    for (int d = 0; d < Kb; d++) {
+        const int s = hb + d;
+        for (u32 c0 = 0; c0 < (1u << hb); c0++) {
+            u32 r = 0;
+            for (int b = 0; b < hb; b++) r |= ((c0 >> b) & 1u) << (hb - 1 - b);
+            for (u32 g = 0; g < (1u << d); g++) out[((size_t)1 << s) + ((size_t)c0 << d) + g] = in[((size_t)1 << s) + ((size_t)r << d) + g];
+        }
+    }
+}
+
+struct ntt_host_tabs_t {  // every table of one limb (host copies)
+    std::vector<twd_t> W, Wi, Wb, Wib;
+    std::vector<ftwd_t> Wd, Wid, Wdb, Widb;
+};
+
 inline int build_ntt_tables(int64_t N, u64 q, u64 psi, std::vector<twd_t>& W, std::vector<twd_t>& Wi, ntt_limb_t* L,
                             std::vector<ftwd_t>* Wd = nullptr, std::vector<ftwd_t>* Wid = nullptr) {
     using namespace hostmath;
@@ -44,6 +65,7 @@ inline int build_ntt_tables(int64_t N, u64 q, u64 psi, std::vector<twd_t>& W, st
     L->pinvd = 1.0 / (double)q;
     L->Wd = nullptr;
     L->Winvd = nullptr;
+    L->Wb = nullptr; L->Winvb = nullptr; L->Wdb = nullptr; L->Winvdb = nullptr;
     if (q < TFHE_FP_QMAX && Wd && Wid) {
         Wd->resize((size_t)N);
         Wid->resize((size_t)N);
@@ -55,6 +77,31 @@ inline int build_ntt_tables(int64_t N, u64 q, u64 psi, std::vector<twd_t>& W, st
         L->w1inv_ninv_d = ftw_t{(double)L->w1inv_ninv.w};
         L->Wd = Wd->data();
         L->Winvd = Wid->data();
+    }
+    return 0;
+}
+
+// all tables of a limb, including the boundary-permuted copies for the register-blocked geometry of this N
+inline int build_ntt_tables_all(int64_t N, u64 q, u64 psi, ntt_host_tabs_t& T, ntt_limb_t* L) {
+    int rc = build_ntt_tables(N, q, psi, T.W, T.Wi, L, &T.Wd, &T.Wid);
+    if (rc) return rc;
+    int logN = 0;
+    while ((1ll << logN) < N) logN++;
+    if (logN >= 10 && logN <= 14) {
+        const int logt = logt_for(logN);
+        // forward last pass and inverse first pass cover the same stages: K = boundary pass width
+        int s0 = 0, Kb = 0;
+        while (s0 < logN) { Kb = pass_k_fwd(logN, logt, s0); s0 += Kb; }
+        if (Kb == pass_k_inv(logN, logt, logN)) {
+            permute_boundary(T.W, T.Wb, logN, Kb);
+            permute_boundary(T.Wi, T.Wib, logN, Kb);
+            L->Wb = T.Wb.data(); L->Winvb = T.Wib.data();
+            if (L->Wd) {
+                permute_boundary(T.Wd, T.Wdb, logN, Kb);
+                permute_boundary(T.Wid, T.Widb, logN, Kb);
+                L->Wdb = T.Wdb.data(); L->Winvdb = T.Widb.data();
+            }
+        }
     }
     return 0;
 }

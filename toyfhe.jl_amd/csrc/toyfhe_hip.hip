@@ -289,41 +289,33 @@ int tfhe_ctx_create(int64_t N, int L, const uint64_t* q, const uint64_t* psi, tf
     c->q.assign(q, q + L);
     c->psi.resize(L);
     c->limbs_host.resize(L);
-    std::vector<twd_t> W, Wi;
-    std::vector<ftwd_t> Wd, Wid;
+    ntt_host_tabs_t HT;
+    auto up = [&](const void* host, size_t bytes, const void** dev) -> bool {
+        if (!host || !bytes) { *dev = nullptr; return true; }
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess) return false;
+        c->tabs.push_back(d);
+        if (hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
+        *dev = d;
+        return true;
+    };
     for (int l = 0; l < L; l++) {
         const u64 ql = q[l];
         u64 p = (psi && psi[l]) ? psi[l] : minimal_primitive_root(ql, 2 * (u64)N);
         ntt_limb_t& LL = c->limbs_host[l];
-        if (build_ntt_tables(N, ql, p, W, Wi, &LL, &Wd, &Wid) != 0) {  // pow2_cyc_rings.jl:31,61 (+ primitivity: psi^N == -1)
+        if (build_ntt_tables_all(N, ql, p, HT, &LL) != 0) {  // pow2_cyc_rings.jl:31,61 (+ primitivity: psi^N == -1)
             tfhe_ctx_destroy(c);
             return fail(TFHE_E_BADARG, "psi[%d]=%llu is not a primitive 2N-th root of unity mod q[%d]", l, (unsigned long long)p, l);
         }
         c->psi[l] = p;
-        twd_t *dW = nullptr, *dWi = nullptr;
-        if (hipMalloc(&dW, N * sizeof(twd_t)) != hipSuccess || hipMalloc(&dWi, N * sizeof(twd_t)) != hipSuccess) {
+        const size_t tb = (size_t)N * sizeof(twd_t), fb = (size_t)N * sizeof(ftwd_t);
+        bool ok = up(HT.W.data(), tb, (const void**)&LL.W) && up(HT.Wi.data(), tb, (const void**)&LL.Winv) &&
+                  up(LL.Wb ? HT.Wb.data() : nullptr, tb, (const void**)&LL.Wb) && up(LL.Winvb ? HT.Wib.data() : nullptr, tb, (const void**)&LL.Winvb) &&
+                  up(LL.Wd ? HT.Wd.data() : nullptr, fb, (const void**)&LL.Wd) && up(LL.Winvd ? HT.Wid.data() : nullptr, fb, (const void**)&LL.Winvd) &&
+                  up(LL.Wdb ? HT.Wdb.data() : nullptr, fb, (const void**)&LL.Wdb) && up(LL.Winvdb ? HT.Widb.data() : nullptr, fb, (const void**)&LL.Winvdb);
+        if (!ok) {
             tfhe_ctx_destroy(c);
-            return fail(TFHE_E_HIP, "hipMalloc of twiddle tables failed (no usable HIP device?)");
-        }
-        c->tabs.push_back(dW); c->tabs.push_back(dWi);
-        if (hipMemcpy(dW, W.data(), N * sizeof(twd_t), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dWi, Wi.data(), N * sizeof(twd_t), hipMemcpyHostToDevice) != hipSuccess) {
-            tfhe_ctx_destroy(c);
-            return fail(TFHE_E_HIP, "hipMemcpy of twiddle tables failed");
-        }
-        LL.W = dW;
-        LL.Winv = dWi;
-        if (LL.Wd) {  // fp64 twins of the tables
-            ftwd_t *fW = nullptr, *fWi = nullptr;
-            if (hipMalloc(&fW, N * sizeof(ftwd_t)) != hipSuccess || hipMalloc(&fWi, N * sizeof(ftwd_t)) != hipSuccess ||
-                hipMemcpy(fW, Wd.data(), N * sizeof(ftwd_t), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(fWi, Wid.data(), N * sizeof(ftwd_t), hipMemcpyHostToDevice) != hipSuccess) {
-                tfhe_ctx_destroy(c);
-                return fail(TFHE_E_HIP, "allocating fp64 twiddle tables failed");
-            }
-            c->tabs.push_back(fW); c->tabs.push_back(fWi);
-            LL.Wd = fW;
-            LL.Winvd = fWi;
+            return fail(TFHE_E_HIP, "allocating the twiddle tables failed (no usable HIP device?)");
         }
     }
     if (hipMalloc(&c->limbs_dev, L * sizeof(ntt_limb_t)) != hipSuccess) { tfhe_ctx_destroy(c); return fail(TFHE_E_HIP, "hipMalloc failed"); }
