@@ -197,3 +197,4 @@ def test_bfv_fast_path_bodies(bits, ns, np_):
         for l, p in enumerate(pb):
             y[0, l, k] = (x * tinv) % big.Q % p
     assert np.array_equal(emul.bfv_fast(qs, pb, t, y, N, contract=True), ref_cpu.contract(cb, cs, t, y))
+

@@ -53,6 +53,13 @@ TFHE_HD u32 lds_phi(u32 j) {
     if (LOGB - LOGT == 5) return j + 2u * (j >> 6) + (j >> 10);
     return j + 4u * (j >> 6) + (j >> 9);
 }
+// phi is additive over disjoint bit fields (each term is a shift), so the address of element r of a register set
+// is phi(base) + phi(r << LO) with the second term a compile-time constant: one address computation per set
+// instead of one per access.
+template <int LOGB, int LOGT>
+constexpr u32 lds_phi_c(u32 j) {
+    return (LOGB - LOGT == 5) ? (j + 2u * (j >> 6) + (j >> 10)) : (j + 4u * (j >> 6) + (j >> 9));
+}
 template <int LOGB, int LOGT>
 constexpr u32 lds_words() {
     constexpr u32 m = (1u << LOGB) - 1;
@@ -97,6 +104,10 @@ struct ntt_limb_t {   // per-limb constants (device copy lives in the context)
     const twd_t* Winvb;
     const ftwd_t* Wdb;
     const ftwd_t* Winvdb;
+    // same idea for the split kernels (a 2^14 transform as two 2^13 half-problems, see k_ntt_fwd_split14): the
+    // boundary pass of each half permuted within its half of every stage block
+    const twd_t* Wbs;
+    const ftwd_t* Wdbs;
 };
 
 // digit lift of the RNS key-switch decomposition (see ntt_io_t below)
@@ -123,6 +134,12 @@ struct ArithInt {
         tw_t ninv, w1n;
     };
     static TFHE_HD ctx make(const ntt_limb_t& L) { return ctx{L.q, L.W, L.Winv, L.Wb, L.Winvb, L.ninv, L.w1inv_ninv}; }
+    static TFHE_HD ctx make_split(const ntt_limb_t& L) { return ctx{L.q, L.W, L.Winv, L.Wbs, nullptr, L.ninv, L.w1inv_ninv}; }
+    // top stage of a split transform: lo +/- W[1]*hi, result in the policy's lazy range
+    static TFHE_HD elem top_stage(u64 lo, u64 hi, u32 sb, const ctx& c) {
+        const u64 t = shoup_lazy(hi, ld_tw(c.W, 1), c.q);  // [0,2q)
+        return sb ? lo + 2 * c.q - t : lo + t;              // < 3q, inside the forward range [0,4q)
+    }
     static TFHE_HD tw ld_fwd_b(const ctx& c, u32 i) { return ld_tw(c.Wb, i); }
     static TFHE_HD tw ld_inv_b(const ctx& c, u32 i) { return ld_tw(c.Winvb, i); }
     static TFHE_HD bool has_b(const ctx& c) { return c.Wb != nullptr; }
@@ -158,6 +175,13 @@ struct ArithFp {
     };
     static TFHE_HD ctx make(const ntt_limb_t& L) {
         return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.Wdb, L.Winvdb, L.ninv_d, L.w1inv_ninv_d, L.q};
+    }
+    static TFHE_HD ctx make_split(const ntt_limb_t& L) {
+        return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.Wdbs, nullptr, L.ninv_d, L.w1inv_ninv_d, L.q};
+    }
+    static TFHE_HD elem top_stage(u64 lo, u64 hi, u32 sb, const ctx& c) {
+        const double a = from_global(lo, c), t = fp_mulmod_c(from_global(hi, c), ld(c.W, 1), c.p, c.pinv);
+        return fp_reduce(sb ? a - t : a + t, c.p, c.pinv);
     }
     // centred representative: keeps |v| <= p/2 at the start of the first pass (range budget of a 5-stage pass)
     static TFHE_HD elem from_global(u64 x, const ctx& c) {
@@ -268,41 +292,53 @@ TFHE_HD void fwd_load_tw(typename A::tw* tw, const typename A::ctx& C, u32 tid, 
     }
 }
 // raw 64-bit words of the operands (global: residues; LDS: the policy's element bits)
-template <int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST>
+template <int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int USEL = -1>
 TFHE_HD void fwd_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, const lift_t* lift = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
+        if (USEL >= 0 && u != USEL) continue;
         u32 c0, hi, base;
         G::template coords<LAST>(tid, u, c0, hi, base);
+        const u32 pb = FIRST ? 0u : lds_phi<LOGB, LOGT>(base);
 #pragma unroll
         for (int r = 0; r < G::R; r++) {
             const u32 j = base + ((u32)r << G::LO);
-            raw[u * G::R + r] = FIRST ? gsrc[j] : lds[lds_phi<LOGB, LOGT>(j)];
+            raw[u * G::R + r] = FIRST ? gsrc[j] : lds[pb + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)];
         }
     }
     (void)lift;
 }
 // Butterflies of the pass.  Twiddles of stages d < PF come from `twp` (requested ahead by the caller);
 // the others are loaded here (the compiler schedules those loads).
-template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int PF>
+template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int PF, int USEL = -1, bool SPLIT = false>
 TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
-                         u32 pre, const lift_t* lift = nullptr) {
+                         u32 pre, const lift_t* lift = nullptr, const u64* raw_hi = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
-    const bool use_b = LAST && pre == 1u && A::has_b(C);  // permuted boundary table (whole-transform blocks only)
-    if (FIRST && lift) {  // digit lift: all conversions first, then the butterflies (register pressure)
+    // permuted boundary table: whole-transform blocks (pre == 1) or the halves of a split transform (pre = 2 + sb,
+    // with the split-permuted copy in C.Wb)
+    const bool use_b = LAST && (pre == 1u || SPLIT) && A::has_b(C);
+    if (FIRST && SPLIT) {  // top stage of the 2^(LOGB+1) transform on the fly: v = lo +/- W[1] hi
+#pragma unroll
+        for (int i = 0; i < G::E; i++) {
+            const u64 lo = lift ? lift_digit(raw[i], *lift) : raw[i], hi = lift ? lift_digit(raw_hi[i], *lift) : raw_hi[i];
+            v[i] = A::top_stage(lo, hi, pre & 1u, C);
+        }
+        TFHE_SCHED_FENCE();
+    } else if (FIRST && lift) {  // digit lift: all conversions first, then the butterflies (register pressure)
 #pragma unroll
         for (int i = 0; i < G::E; i++) v[i] = A::from_global_lift(raw[i], C, *lift);
         TFHE_SCHED_FENCE();
     }
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
+        if (USEL >= 0 && u != USEL) continue;
         u32 c0, hi, base;
         G::template coords<LAST>(tid, u, c0, hi, base);
         typename A::elem* vv = v + u * G::R;
 #pragma unroll
         for (int r = 0; r < G::R; r++) {
-            if (FIRST && lift) continue;
+            if (FIRST && (lift || SPLIT)) continue;
             vv[r] = FIRST ? A::from_global(raw[u * G::R + r], C) : A::from_lds(raw[u * G::R + r]);
         }
 #pragma unroll
@@ -311,7 +347,7 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
 #pragma unroll
             for (int g = 0; g < (1 << d); g++) {
                 const typename A::tw w = d < PF ? twp[u * G::NTW + (1 << d) - 1 + g]
-                                         : (LAST && use_b) ? A::ld_fwd_b(C, (1u << (S0 + d)) + (c0 << d) + (u32)g)
+                                         : (LAST && use_b) ? A::ld_fwd_b(C, (pre << (S0 + d)) + (c0 << d) + (u32)g)
                                                            : A::ld_fwd(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
 #pragma unroll
                 for (int i = 0; i < half; i++) {
@@ -326,14 +362,16 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
         }
     }
 }
-template <class A, int LOGB, int LOGT, int S0, int K, bool LAST>
+template <class A, int LOGB, int LOGT, int S0, int K, bool LAST, int USEL = -1>
 TFHE_HD void fwd_store(typename A::elem* v, u64* lds, u64* gdst, const typename A::ctx& C, u32 tid, int x, u32 sb_rev) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
     static_assert(!LAST || G::LO == 0, "LAST pass must end at stage LOGB-1");
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
+        if (USEL >= 0 && u != USEL) continue;
         u32 c0, hi, base;
         G::template coords<LAST>(tid, u, c0, hi, base);
+        const u32 pb = LAST ? 0u : lds_phi<LOGB, LOGT>(base);
 #pragma unroll
         for (int r = 0; r < G::R; r++) {
             typename A::elem e = v[u * G::R + r];
@@ -342,7 +380,7 @@ TFHE_HD void fwd_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
                 gdst[((u64)nat << x) + sb_rev] = A::out_fwd(e, C);
             } else {
                 A::range_fwd(e, C);
-                lds[lds_phi<LOGB, LOGT>(base + ((u32)r << G::LO))] = A::to_lds(e);
+                lds[pb + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)] = A::to_lds(e);
             }
         }
     }
@@ -387,19 +425,20 @@ TFHE_HD void inv_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, i
                 const u32 nat = (brev_bits((u32)r, K) << (LOGB - K)) + c0;
                 raw[u * G::R + r] = gsrc[((u64)nat << x) + sb_rev];
             } else {
-                raw[u * G::R + r] = lds[lds_phi<LOGB, LOGT>(base + ((u32)r << G::LO))];
+                raw[u * G::R + r] = lds[lds_phi<LOGB, LOGT>(base) + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)];
             }
         }
     }
 }
 // Inverse butterflies (stage K-1 first).  Stages d >= K-PF come from `twp`; the others are loaded here.
-template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE, int PF>
+template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE, int PF, int USEL = -1>
 TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
                          u32 pre) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
     const bool use_b = FROM_GLOBAL && pre == 1u && A::has_b(C);
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
+        if (USEL >= 0 && u != USEL) continue;
         u32 c0, hi, base;
         G::template coords<FROM_GLOBAL>(tid, u, c0, hi, base);
         typename A::elem* vv = v + u * G::R;
@@ -434,7 +473,7 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
         }
     }
 }
-template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE>
+template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE, int USEL = -1>
 TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename A::ctx& C, u32 tid,
                        const u64* addend = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
@@ -449,6 +488,7 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
     }
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
+        if (USEL >= 0 && u != USEL) continue;
         u32 c0, hi, base;
         G::template coords<FROM_GLOBAL>(tid, u, c0, hi, base);
 #pragma unroll
@@ -461,7 +501,7 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
             } else {
                 typename A::elem e = v[u * G::R + r];
                 A::range_inv(e, C);
-                lds[lds_phi<LOGB, LOGT>(j)] = A::to_lds(e);
+                lds[lds_phi<LOGB, LOGT>(base) + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)] = A::to_lds(e);
             }
         }
     }
