@@ -87,31 +87,57 @@ struct bfv_fast_tab_t {
     u64 c_A2[TFHE_FAST_MAX];            // P mod q_i
     u64 c_halfT[TFHE_FAST_MAX];         // floor(P/2) mod q_i
     int lazy_q, lazy_p;                 // products that may be accumulated before a reduction (sources q / P)
+    int narrow;                         // every modulus of ℛ and P is below 2^52: carry-free split accumulation
+    // ---- narrow path (bfv_expand_narrow / bfv_contract_narrow): constants pre-split into 26-bit halves, packed
+    //      lo26 | hi26 << 32, with every subtraction folded in as a negated constant so that a whole output is ONE
+    //      carry-free product-sum followed by ONE Barrett reduction ----
+    u64 n_eC[TFHE_FAST_MAX][TFHE_FAST_MAX];     // [i][j]  (q/q_i) mod p_j
+    u64 n_eNegA[TFHE_FAST_MAX];                 // -(q mod p_j)                 (times alpha)
+    u64 n_eNegHalf[TFHE_FAST_MAX];              // -(floor(q/2) mod p_j)        (plain value, added once)
+    u64 n_cA2[TFHE_FAST_MAX];                   // t q^-1 (P/p_j)^-1 mod p_j    (times the P-limb input)
+    u64 n_cNegC1[TFHE_FAST_MAX][TFHE_FAST_MAX]; // [i][j]  -(q/q_i) q^-1 (P/p_j)^-1 mod p_j
+    u64 n_cA1[TFHE_FAST_MAX];                   // (P/p_j)^-1 mod p_j           (times alpha_1)
+    u64 n_cC2[TFHE_FAST_MAX][TFHE_FAST_MAX];    // [j][i]  (P/p_j) mod q_i
+    u64 n_cNegA2[TFHE_FAST_MAX];                // -(P mod q_i)                 (times alpha_2)
+    u64 n_cNegHalf[TFHE_FAST_MAX];              // -(floor(P/2) mod q_i)        (plain)
     // exact-alpha tables (word arrays in global memory)
     const u64 *Mq, *Aq, *Mp, *Ap;
     int nwq, nwp;
 };
 
-template <int K>
+template <int K, bool NARROW>
 TFHE_HD u64 mac_reduce(const u64 (&xi)[K], const u64* col, int stride, const barrett_t& bt, int lazy) {
-    acc128 acc{0, 0};
-    u64 sum = 0;
-    int pending = 0;
+    if constexpr (NARROW) {  // every modulus below 2^52: carry-free 26-bit-split accumulation (modarith.h acc52)
+        static_assert(K <= 16, "acc52 holds at most 16 terms");
+        acc52 a{0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < K; j++) {
-        acc_mac(acc, xi[j], col[(size_t)j * stride]);
-        if (++pending == lazy) {
-            sum = addmod(sum, barrett_reduce128(acc.lo, acc.hi, bt), bt.q);
-            acc = acc128{0, 0};
-            pending = 0;
+        for (int j = 0; j < K; j++) {
+            const u64 c = col[(size_t)j * stride];
+            acc52_mac(a, (u32)xi[j] & 0x3ffffffu, (u32)(xi[j] >> 26), (u32)c & 0x3ffffffu, (u32)(c >> 26));
         }
+        u64 lo, hi;
+        acc52_fold(a, lo, hi);
+        return barrett_reduce128(lo, hi, bt);
+    } else {
+        acc128 acc{0, 0};
+        u64 sum = 0;
+        int pending = 0;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            acc_mac(acc, xi[j], col[(size_t)j * stride]);
+            if (++pending == lazy) {
+                sum = addmod(sum, barrett_reduce128(acc.lo, acc.hi, bt), bt.q);
+                acc = acc128{0, 0};
+                pending = 0;
+            }
+        }
+        if (pending) sum = addmod(sum, barrett_reduce128(acc.lo, acc.hi, bt), bt.q);
+        return sum;
     }
-    if (pending) sum = addmod(sum, barrett_reduce128(acc.lo, acc.hi, bt), bt.q);
-    return sum;
 }
 
 // src: ℛ limb i of this coefficient at src[i*ls]; dst: ℛbig limb l at dst[l*ld]
-template <int NS, int NP>
+template <int NS, int NP, bool NARROW = false>
 TFHE_HD void bfv_expand_fast(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
     u64 x[NS], xi[NS];
 #pragma unroll
@@ -127,13 +153,13 @@ TFHE_HD void bfv_expand_fast(const bfv_fast_tab_t& B, const u64* src, size_t ls,
 #pragma unroll
     for (int j = 0; j < NP; j++) {
         const barrett_t& bt = B.pb[j];
-        u64 r = mac_reduce<NS>(xi, &B.e_C[0][j], TFHE_FAST_MAX, bt, B.lazy_q);
+        u64 r = mac_reduce<NS, NARROW>(xi, &B.e_C[0][j], TFHE_FAST_MAX, bt, B.lazy_q);
         r = submod(r, mulmod((u64)alpha, B.e_A[j], bt), bt.q);
         dst[(size_t)B.pos_p[j] * ld] = submod(r, B.e_halfT[j], bt.q);
     }
 }
 
-template <int NS, int NP>
+template <int NS, int NP, bool NARROW = false>
 TFHE_HD void bfv_contract_fast(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
     u64 xi[NS];
 #pragma unroll
@@ -147,7 +173,7 @@ TFHE_HD void bfv_contract_fast(const bfv_fast_tab_t& B, const u64* src, size_t l
     for (int j = 0; j < NP; j++) {  // ξ'_j of w + floor(P/2) in basis P
         const barrett_t& bt = B.pb[j];
         u64 v = addmod(shoup_full(src[(size_t)B.pos_p[j] * ls], B.c_a2[j], bt.q), B.c_b2[j], bt.q);
-        v = submod(v, mac_reduce<NS>(xi, &B.c_C1[0][j], TFHE_FAST_MAX, bt, B.lazy_q), bt.q);
+        v = submod(v, mac_reduce<NS, NARROW>(xi, &B.c_C1[0][j], TFHE_FAST_MAX, bt, B.lazy_q), bt.q);
         xp[j] = addmod(v, mulmod((u64)a1, B.c_A1[j], bt), bt.q);
     }
     u32 a2 = conv_alpha_fast<NP>(xp, B.rho_p, B.sh_p, frac);
@@ -155,8 +181,74 @@ TFHE_HD void bfv_contract_fast(const bfv_fast_tab_t& B, const u64* src, size_t l
 #pragma unroll
     for (int i = 0; i < NS; i++) {
         const barrett_t& bt = B.qb[i];
-        u64 r = mac_reduce<NP>(xp, &B.c_C2[0][i], TFHE_FAST_MAX, bt, B.lazy_p);
+        u64 r = mac_reduce<NP, NARROW>(xp, &B.c_C2[0][i], TFHE_FAST_MAX, bt, B.lazy_p);
         r = submod(r, mulmod((u64)a2, B.c_A2[i], bt), bt.q);
         dst[(size_t)i * ld] = submod(r, B.c_halfT[i], bt.q);
+    }
+}
+
+// ---- narrow path: every modulus below 2^52 ----
+TFHE_HD u64 pack26(u64 c) { return (c & 0x3ffffffull) | ((c >> 26) << 32); }
+TFHE_HD void acc52_macp(acc52& a, u64 x, u64 cpacked) {
+    acc52_mac(a, (u32)x & 0x3ffffffu, (u32)(x >> 26), (u32)cpacked, (u32)(cpacked >> 32));
+}
+TFHE_HD u64 acc52_reduce(const acc52& a, const barrett_t& bt) {
+    u64 lo, hi;
+    acc52_fold(a, lo, hi);
+    return barrett_reduce128(lo, hi, bt);
+}
+
+template <int NS, int NP>
+TFHE_HD void bfv_expand_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
+    static_assert(NS + 2 <= 16 && NP + 2 <= 16, "acc52 term budget");
+    u64 x[NS], xi[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        x[i] = src[(size_t)i * ls];
+        xi[i] = shoup_full(addmod(x[i], B.e_half[i], B.q[i]), B.e_inv[i], B.q[i]);
+    }
+    u64 frac;
+    u32 alpha = conv_alpha_fast<NS>(xi, B.rho_q, B.sh_q, frac);
+    if (frac + 2ull * NS < frac) alpha = conv_alpha_exact<NS>(xi, B.Mq, B.Aq, B.nwq, alpha);
+#pragma unroll
+    for (int i = 0; i < NS; i++) dst[(size_t)B.pos_s[i] * ld] = x[i];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        acc52 a{B.n_eNegHalf[j], 0, 0};
+#pragma unroll
+        for (int i = 0; i < NS; i++) acc52_macp(a, xi[i], B.n_eC[i][j]);
+        acc52_macp(a, (u64)alpha, B.n_eNegA[j]);
+        dst[(size_t)B.pos_p[j] * ld] = acc52_reduce(a, B.pb[j]);
+    }
+}
+
+template <int NS, int NP>
+TFHE_HD void bfv_contract_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
+    u64 xi[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++)  // ξ_i of r = (t y + h) mod q
+        xi[i] = addmod(shoup_full(src[(size_t)B.pos_s[i] * ls], B.c_a1[i], B.q[i]), B.c_b1[i], B.q[i]);
+    u64 frac;
+    u32 a1 = conv_alpha_fast<NS>(xi, B.rho_q, B.sh_q, frac);
+    if (frac + 2ull * NS < frac) a1 = conv_alpha_exact<NS>(xi, B.Mq, B.Aq, B.nwq, a1);
+    u64 xp[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {  // ξ'_j of w + floor(P/2) in basis P: one product-sum, one reduction
+        acc52 a{B.c_b2[j], 0, 0};
+        acc52_macp(a, src[(size_t)B.pos_p[j] * ls], B.n_cA2[j]);
+#pragma unroll
+        for (int i = 0; i < NS; i++) acc52_macp(a, xi[i], B.n_cNegC1[i][j]);
+        acc52_macp(a, (u64)a1, B.n_cA1[j]);
+        xp[j] = acc52_reduce(a, B.pb[j]);
+    }
+    u32 a2 = conv_alpha_fast<NP>(xp, B.rho_p, B.sh_p, frac);
+    if (frac + 2ull * NP < frac) a2 = conv_alpha_exact<NP>(xp, B.Mp, B.Ap, B.nwp, a2);
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        acc52 a{B.n_cNegHalf[i], 0, 0};
+#pragma unroll
+        for (int j = 0; j < NP; j++) acc52_macp(a, xp[j], B.n_cC2[j][i]);
+        acc52_macp(a, (u64)a2, B.n_cNegA2[i]);
+        dst[(size_t)i * ld] = acc52_reduce(a, B.qb[i]);
     }
 }

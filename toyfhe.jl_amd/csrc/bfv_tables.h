@@ -185,6 +185,26 @@ inline bool build_bfv_fast_host(const std::vector<u64>& qs, const std::vector<u6
         }
     }
     auto lazy_of = [](int bits, int k) { const int room = 62 - bits; return std::max(1, std::min(k, room >= 20 ? (1 << 20) : (1 << std::max(0, room)))); };
+    B.narrow = (maxq <= 52 && maxp <= 52 && ns + 2 <= 16 && np + 2 <= 16) ? 1 : 0;
+    if (B.narrow) {
+        auto neg = [](u64 c, u64 m) { return c ? m - c : 0; };
+        for (int j = 0; j < np; j++) {
+            const u64 pj = P[j];
+            B.n_eNegA[j] = pack26(neg(B.e_A[j], pj));
+            B.n_eNegHalf[j] = neg(B.e_halfT[j], pj);
+            B.n_cA2[j] = pack26(B.c_a2[j].w);
+            B.n_cA1[j] = pack26(B.c_A1[j]);
+            for (int i = 0; i < ns; i++) {
+                B.n_eC[i][j] = pack26(B.e_C[i][j]);
+                B.n_cNegC1[i][j] = pack26(neg(B.c_C1[i][j], pj));
+                B.n_cC2[j][i] = pack26(B.c_C2[j][i]);
+            }
+        }
+        for (int i = 0; i < ns; i++) {
+            B.n_cNegA2[i] = pack26(neg(B.c_A2[i], qs[i]));
+            B.n_cNegHalf[i] = neg(B.c_halfT[i], qs[i]);
+        }
+    }
     B.lazy_q = lazy_of(maxq, ns);
     B.lazy_p = lazy_of(maxp, np);
     B.nwq = (int)q.size();

@@ -29,6 +29,56 @@ __device__ __forceinline__ void fwd_schedule(u64* lds, const u64* gsrc, u64* gds
         fwd_schedule<A, LOGB, LOGT, S0 + K>(lds, gsrc, gdst, C, tid, pre, x, sbrev, lift);
     }
 }
+// ---- same, with the twiddles of pass p+1 requested before the LDS exchange that ends pass p (8-byte fp64 twiddles:
+// a whole pass's set fits the register budget of a 512-thread workgroup) ----
+template <class A, int LOGB, int LOGT, int S0>
+__device__ __forceinline__ void fwd_schedule_ptw(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
+                                                 u32 pre, const lift_t* lift, const typename A::tw* tw_cur) {
+    constexpr int K = pass_k_fwd(LOGB, LOGT, S0);
+    constexpr bool FIRST = (S0 == 0), LAST = (S0 + K == LOGB);
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+    u64 raw[G::E];
+    typename A::elem v[G::E];
+    fwd_load_data<LOGB, LOGT, S0, K, FIRST, LAST>(raw, lds, gsrc, tid);
+    fwd_compute<A, LOGB, LOGT, S0, K, FIRST, LAST, FIRST ? 0 : K>(v, raw, tw_cur, C, tid, pre, FIRST ? lift : nullptr);
+    if constexpr (!LAST) {
+        constexpr int K2 = pass_k_fwd(LOGB, LOGT, S0 + K);
+        typedef pgeom<LOGB, LOGT, S0 + K, K2> G2;
+        typename A::tw tw_next[G2::SETS * G2::NTW];
+        fwd_load_tw<A, LOGB, LOGT, S0 + K, K2, (S0 + K + K2 == LOGB)>(tw_next, C, tid, pre);
+        fwd_store<A, LOGB, LOGT, S0, K, false>(v, lds, gdst, C, tid, 0, 0u);
+        __syncthreads();
+        fwd_schedule_ptw<A, LOGB, LOGT, S0 + K>(lds, gsrc, gdst, C, tid, pre, lift, tw_next);
+    } else {
+        fwd_store<A, LOGB, LOGT, S0, K, true>(v, lds, gdst, C, tid, 0, 0u);
+    }
+}
+template <class A, int LOGB, int LOGT, int SEND>
+__device__ __forceinline__ void inv_schedule_ptw(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
+                                                 u32 pre, const u64* addend, const typename A::tw* tw_cur) {
+    constexpr int K = pass_k_inv(LOGB, LOGT, SEND);
+    constexpr int S0 = SEND - K;
+    constexpr bool FROM_GLOBAL = (SEND == LOGB), TO_GLOBAL = (S0 == 0);
+    typedef pgeom<LOGB, LOGT, S0, K> G;
+    u64 raw[G::E];
+    typename A::elem v[G::E];
+    inv_load_data<LOGB, LOGT, S0, K, FROM_GLOBAL>(raw, lds, gsrc, tid, 0, 0u);
+    // the last pass (S0 == 0) has workgroup-uniform twiddles: loaded inside (scalar); the first one loads its own
+    // alongside the operands; the middle ones come prefetched
+    inv_compute<A, LOGB, LOGT, S0, K, FROM_GLOBAL, true, (TO_GLOBAL || FROM_GLOBAL) ? 0 : K>(v, raw, tw_cur, C, tid, pre);
+    if constexpr (!TO_GLOBAL) {
+        constexpr int K2 = pass_k_inv(LOGB, LOGT, S0);
+        typedef pgeom<LOGB, LOGT, S0 - K2, K2> G2;
+        typename A::tw tw_next[G2::SETS * G2::NTW];
+        if constexpr (S0 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S0 - K2, K2, false>(tw_next, C, tid, pre);
+        inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, true>(v, lds, gdst, C, tid, nullptr);
+        __syncthreads();
+        inv_schedule_ptw<A, LOGB, LOGT, S0>(lds, gsrc, gdst, C, tid, pre, addend, tw_next);
+    } else {
+        inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, true>(v, lds, gdst, C, tid, addend);
+    }
+}
+
 template <class A, int LOGB, int LOGT, int SEND, bool SCALE>
 __device__ __forceinline__ void inv_schedule(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
                                              u32 pre, int x, u32 sbrev, const u64* addend) {
@@ -65,8 +115,15 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_block(const u64* __restri
         }
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         if (item != blockIdx.x) __syncthreads();  // the previous item's last pass has read LDS
-        fwd_schedule<A, LOGB, LOGT, 0>(lds, src + srow * ntot + ((size_t)sb << LOGB), dst + drow * ntot, C, threadIdx.x,
-                                       (1u << x) + sb, x, brev_bits(sb, x), lift);
+#ifdef TFHE_FWD_PTW  // measured slower than the plain schedule for the forward transform (tools/ntt_ablate.hip)
+        if constexpr (A::whole_block_only)
+#else
+        if constexpr (false)
+#endif
+            fwd_schedule_ptw<A, LOGB, LOGT, 0>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, lift, nullptr);
+        else
+            fwd_schedule<A, LOGB, LOGT, 0>(lds, src + srow * ntot + ((size_t)sb << LOGB), dst + drow * ntot, C, threadIdx.x,
+                                           (1u << x) + sb, x, brev_bits(sb, x), lift);
     }
 }
 template <class A, int LOGB, int LOGT, int IOMODE>
@@ -89,7 +146,11 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restri
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         if (item != blockIdx.x) __syncthreads();
         if constexpr (A::whole_block_only) {  // the fp64 variant is only dispatched for x == 0
+#ifdef TFHE_NO_PTW
             inv_schedule<A, LOGB, LOGT, LOGB, true>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, 0, 0u, addend);
+#else
+            inv_schedule_ptw<A, LOGB, LOGT, LOGB>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, addend, nullptr);
+#endif
         } else {
             if (x == 0)
                 inv_schedule<A, LOGB, LOGT, LOGB, true>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, 0, 0u, addend);
@@ -97,6 +158,308 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restri
                 inv_schedule<A, LOGB, LOGT, LOGB, false>(lds, src + srow * ntot, dst + drow * ntot + ((size_t)sb << LOGB), C,
                                                          threadIdx.x, (1u << x) + sb, x, brev_bits(sb, x), nullptr);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Staged variant (whole-transform blocks, x == 0): the workgroup keeps walking items, and while it runs
+// the LAST pass of item i out of registers the LDS is idle -- so the 128 KiB row of item i+1 is copied
+// HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write) underneath that pass.  The first
+// pass of item i+1 then reads its operands from LDS (lane-linear image of the row: conflict-free for the
+// stride-1-across-lanes first-pass patterns) instead of waiting on HBM.  Order inside an item:
+//     barrier | pass 1 (operands from the staged row) | barrier | pass-1 results -> LDS | ... | pass-3
+//     operands -> registers | barrier | LDS-DMA of the next row | pass-3 butterflies | wait for the DMA |
+//     stores of item i  (they drain underneath passes 1-2 of item i+1)
+// vmcnt is one in-order counter for loads, so every ordinary vector load whose result is needed while the
+// DMA is in flight (last-pass twiddles, addends) is issued and waited for BEFORE the DMA is started.
+// ------------------------------------------------------------------------------------------------
+#define TFHE_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#ifdef TFHE_TRACE  // design aid (tools/ntt_ablate.hip): shader-clock stamps of one workgroup's phases
+__device__ unsigned long long tfhe_trace[64 * 16];
+#define TFHE_STAMP(k)                                                                                   \
+    do {                                                                                                \
+        if (blockIdx.x == (TFHE_TRACE) && threadIdx.x == 0 && itc < 64) {                               \
+            tfhe_trace[itc * 16 + (k)] = __builtin_amdgcn_s_memtime();                                  \
+            if ((k) == 0) tfhe_trace[itc * 16 + 15] = __builtin_amdgcn_s_memrealtime();                 \
+        }                                                                                               \
+    } while (0)
+#else
+#define TFHE_STAMP(k) ((void)0)
+#endif
+
+__device__ __forceinline__ void glds16(const void* gsrc, u32 lds_byte) {  // one 1-KiB wave-wide piece
+#ifdef TFHE_ABL_NOMEM
+    return;
+#endif
+    u32 keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte)
+                 : "memory");
+}
+// LDS-DMA of one 2^LOGB-word row into the lane-linear LDS image, PER_WAVE 1-KiB pieces per wave; as a progress hook
+// it issues piece k once the butterfly count passes k/PER_WAVE of the pass
+template <int LOGB, int LOGT>
+struct row_stager {
+    static constexpr int PER_WAVE = ((8 << LOGB) / 1024) >> (LOGT - 6);
+    const char* g;
+    u32 l0;
+    bool on;
+    __device__ __forceinline__ row_stager(u64* lds, const u64* grow, u32 tid, bool enable) {
+        const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
+        l0 = (u32)(size_t)(__attribute__((address_space(3))) u64*)lds + wave * (PER_WAVE * 1024u);
+        g = (const char*)grow + (size_t)wave * (PER_WAVE * 1024) + lane * 16;
+        on = enable;
+    }
+    __device__ __forceinline__ void piece(int i) const { glds16(g + i * 1024, l0 + (u32)i * 1024u); }
+    __device__ __forceinline__ void all() const {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; i++) piece(i);
+    }
+    __device__ __forceinline__ void operator()(int before, int after, int total) const {
+        const int lo = PER_WAVE * before / total, hi = PER_WAVE * after / total;
+        if (hi > lo && on) {
+#pragma unroll
+            for (int i = lo; i < hi; i++) piece(i);
+        }
+    }
+};
+// finished residues of the previous item, written out piecewise underneath the first pass of the current one
+template <int LOGB, int LOGT, int K3>
+struct fwd_out_storer {  // forward: natural-order positions of the bit-reversed last-pass map (fwd_store, LAST)
+    const u64* o;
+    u64* g;
+    u32 tid;
+    __device__ __forceinline__ void one(int i) const {
+        constexpr int R3 = 1 << K3;
+        const u32 c0 = (u32)(i / R3) * (1u << LOGT) + tid;
+#ifdef TFHE_ABL_NOMEM
+        asm volatile("" ::"v"(o[i]), "v"(c0));
+        return;
+#endif
+        g[(brev_bits((u32)(i % R3), K3) << (LOGB - K3)) + c0] = o[i];
+    }
+    __device__ __forceinline__ void operator()(int before, int after, int total) const {
+        constexpr int E = 1 << (LOGB - LOGT);
+        const int lo = E * before / total, hi = E * after / total;
+        if (hi > lo && g) {
+#pragma unroll
+            for (int i = lo; i < hi; i++) one(i);
+        }
+    }
+};
+template <int LOGB, int LOGT>
+struct inv_out_storer {  // inverse: element r of thread tid is coefficient tid + r 2^LOGT
+    const u64* o;
+    u64* g;
+    u32 tid;
+    __device__ __forceinline__ void one(int i) const {
+#ifdef TFHE_ABL_NOMEM
+        asm volatile("" ::"v"(o[i]));
+        return;
+#endif
+        g[tid + ((u32)i << LOGT)] = o[i];
+    }
+    __device__ __forceinline__ void operator()(int before, int after, int total) const {
+        constexpr int E = 1 << (LOGB - LOGT);
+        const int lo = E * before / total, hi = E * after / total;
+        if (hi > lo && g) {
+#pragma unroll
+            for (int i = lo; i < hi; i++) one(i);
+        }
+    }
+};
+template <class T>
+__device__ __forceinline__ void pin_vgpr(T& x) { asm volatile("" : "+v"(x)); }
+
+struct item_rows_t {
+    u32 srow, drow, j;
+    bool has_add;
+    u32 arow;
+};
+template <int IOMODE>
+__device__ __forceinline__ item_rows_t item_rows(u32 pl, const limb_sel_t& sel, const ntt_io_t& io, lift_t& lf,
+                                                 const ntt_limb_t* LT) {
+    item_rows_t r{pl, pl, pl % (u32)sel.n, false, 0u};
+    if constexpr (IOMODE == 1) {
+        const u32 per_ct = io.level * io.nw, b = pl / per_ct, rem = pl % per_ct, i = rem / io.nw;
+        r.j = rem % io.nw;
+        r.srow = (b * io.polys + io.polys - 1) * io.level + i;
+        const ntt_limb_t& Li = LT[sel.idx[i]];
+        const ntt_limb_t& Lj = LT[sel.idx[r.j]];
+        lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
+    } else if constexpr (IOMODE == 2) {
+        const u32 g = pl / io.gsz, w = pl % io.gsz;
+        r.srow = g * io.src_gstride + w;
+        r.drow = g * io.dst_gstride + w;
+        r.j = w % (u32)sel.n;
+        r.has_add = w < io.add_rows;
+        r.arow = g * io.add_gstride + w;
+    }
+    return r;
+}
+
+template <class A, int LOGB, int LOGT, int IOMODE>
+__global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_staged(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel,
+                                                               u32 nitems, ntt_io_t io) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
+    static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass schedule expected");
+    typedef pgeom<LOGB, LOGT, K1 + K2, K3> G3;
+    constexpr int E = G3::E;
+    const u32 tid = threadIdx.x;
+    u32 item = blockIdx.x;
+    if (item >= nitems) return;
+    lift_t lf;
+    item_rows_t R = item_rows<IOMODE>(item, sel, io, lf, LT);
+    row_stager<LOGB, LOGT>(lds, src + ((size_t)R.srow << LOGB), tid, true).all();
+    TFHE_WAIT_VM0();
+    u32 itc = 0;
+    (void)itc;
+    u64 o[E];             // finished residues of the previous item ...
+    u64* gprev = nullptr; // ... and where they go: stored underneath pass 1 of the next item
+    for (;;) {
+        const typename A::ctx C = A::make(LT[sel.idx[R.j]]);
+        u64* gdst = dst + ((size_t)R.drow << LOGB);
+        __syncthreads();  // the staged row (every wave's pieces) is in LDS
+        TFHE_STAMP(0);
+        {
+            u64 raw[E];
+            typename A::elem v[E];
+            fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, lds, tid);
+            const fwd_out_storer<LOGB, LOGT, K3> storer{o, gprev, tid};
+            fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0, -1, false, fwd_out_storer<LOGB, LOGT, K3>>(
+                v, raw, nullptr, C, tid, 1u, IOMODE == 1 ? &lf : nullptr, nullptr, storer);
+            __syncthreads();  // every thread has taken its operands out of the staged image
+            TFHE_STAMP(1);
+            fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+        }
+        __syncthreads();
+        TFHE_STAMP(2);
+        typename A::tw tw3[G3::SETS * G3::NTW];
+        fwd_load_tw<A, LOGB, LOGT, K1 + K2, K3, true>(tw3, C, tid, 1u);  // requested early, needed after pass 2
+        ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
+        __syncthreads();
+        TFHE_STAMP(3);
+        const u32 next = item + gridDim.x;
+        {
+            u64 raw[E];
+            typename A::elem v[E];
+            fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(raw, lds, nullptr, tid);
+#pragma unroll
+            for (int i = 0; i < G3::SETS * G3::NTW; i++) pin_vgpr(tw3[i].w);  // twiddles have landed (vmcnt) ...
+#pragma unroll
+            for (int i = 0; i < E; i++) pin_vgpr(raw[i]);                     // ... and so have the operands (lgkmcnt)
+            __syncthreads();  // LDS is free
+            TFHE_STAMP(4);
+            item_rows_t Rn = R;
+            lift_t lfn = lf;
+            if (next < nitems) Rn = item_rows<IOMODE>(next, sel, io, lfn, LT);
+            const row_stager<LOGB, LOGT> stager(lds, src + ((size_t)Rn.srow << LOGB), tid, next < nitems);
+            fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, K3, -1, false, row_stager<LOGB, LOGT>>(v, raw, tw3, C, tid, 1u, nullptr,
+                                                                                                    nullptr, stager);
+#pragma unroll
+            for (int i = 0; i < E; i++) o[i] = A::out_fwd(v[i], C);
+            TFHE_SCHED_FENCE();
+            TFHE_STAMP(6);
+            TFHE_WAIT_VM0();  // own pieces of the next row are in LDS
+            TFHE_STAMP(7);
+            gprev = gdst;
+            R = Rn;
+            lf = lfn;
+        }
+        if (next >= nitems) break;
+        item = next;
+        itc++;
+    }
+    const fwd_out_storer<LOGB, LOGT, K3> last{o, gprev, tid};
+#pragma unroll
+    for (int i = 0; i < E; i++) last.one(i);
+}
+
+template <class A, int LOGB, int LOGT, int IOMODE>
+__global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_staged(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel,
+                                                               u32 nitems, ntt_io_t io) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_inv(LOGB, LOGT, LOGB), K2 = pass_k_inv(LOGB, LOGT, LOGB - K1), K3 = LOGB - K1 - K2;
+    static_assert(K3 >= 1 && pass_k_inv(LOGB, LOGT, K3) == K3, "three-pass schedule expected");
+    typedef pgeom<LOGB, LOGT, 0, K3> G3;
+    constexpr int E = G3::E;
+    const u32 tid = threadIdx.x;
+    u32 item = blockIdx.x;
+    if (item >= nitems) return;
+    lift_t lf;
+    item_rows_t R = item_rows<IOMODE>(item, sel, io, lf, LT);
+    row_stager<LOGB, LOGT>(lds, src + ((size_t)R.srow << LOGB), tid, true).all();
+    TFHE_WAIT_VM0();
+    u32 itc = 0;
+    (void)itc;
+    for (;;) {
+        const typename A::ctx C = A::make(LT[sel.idx[R.j]]);
+        u64* gdst = dst + ((size_t)R.drow << LOGB);
+        __syncthreads();
+        TFHE_STAMP(0);
+        {
+            u64 raw[E];
+            typename A::elem v[E];
+            inv_load_data<LOGB, LOGT, LOGB - K1, K1, true>(raw, lds, lds, tid, 0, 0u);
+            inv_compute<A, LOGB, LOGT, LOGB - K1, K1, true, true, 0>(v, raw, nullptr, C, tid, 1u);
+            __syncthreads();
+            TFHE_STAMP(1);
+            inv_store<A, LOGB, LOGT, LOGB - K1, K1, true, true>(v, lds, nullptr, C, tid);
+        }
+        __syncthreads();
+        TFHE_STAMP(2);
+        ntt_inv_pass<A, LOGB, LOGT, K3, K2, false, false, true>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
+        __syncthreads();
+        TFHE_STAMP(3);
+        const u32 next = item + gridDim.x;
+        {
+            u64 raw[E], add[IOMODE == 2 ? E : 1];
+            typename A::elem v[E];
+            inv_load_data<LOGB, LOGT, 0, K3, false>(raw, lds, nullptr, tid, 0, 0u);
+            const bool has_add = IOMODE == 2 && R.has_add;
+            if constexpr (IOMODE == 2) {
+                if (has_add) {
+                    const u64* ap = io.addend + ((size_t)R.arow << LOGB);
+#pragma unroll
+                    for (int r = 0; r < E; r++) add[r] = ap[tid + ((u32)r << LOGT)];
+#pragma unroll
+                    for (int r = 0; r < E; r++) pin_vgpr(add[r]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < E; i++) pin_vgpr(raw[i]);
+            __syncthreads();  // LDS is free
+            TFHE_STAMP(4);
+            item_rows_t Rn = R;
+            if (next < nitems) Rn = item_rows<IOMODE>(next, sel, io, lf, LT);
+            const row_stager<LOGB, LOGT> stager(lds, src + ((size_t)Rn.srow << LOGB), tid, next < nitems);
+            inv_compute<A, LOGB, LOGT, 0, K3, false, true, 0, -1, row_stager<LOGB, LOGT>>(v, raw, nullptr, C, tid, 1u, stager);
+            u64 o[E];
+#pragma unroll
+            for (int i = 0; i < E; i++) o[i] = A::out_inv_scaled(v[i], C);
+            if constexpr (IOMODE == 2) {
+                if (has_add) {
+#pragma unroll
+                    for (int i = 0; i < E; i++) o[i] = addmod(o[i], add[i], C.q);
+                }
+            }
+            TFHE_SCHED_FENCE();
+            TFHE_STAMP(6);
+            TFHE_WAIT_VM0();
+            TFHE_STAMP(7);
+            static_assert(G3::SETS == 1 && G3::LO == LOGT, "last inverse pass: one register set, stride 2^LOGT");
+#pragma unroll
+            for (int r = 0; r < E; r++) gdst[tid + ((u32)r << LOGT)] = o[r];
+            TFHE_STAMP(8);
+            R = Rn;
+        }
+        if (next >= nitems) break;
+        item = next;
+        itc++;
     }
 }
 
@@ -417,7 +780,8 @@ __global__ __launch_bounds__(256) void k_bfv_expand_fast(const u64* __restrict__
     const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
     const size_t p = blockIdx.x / gx;
     if (k >= n) return;
-    bfv_expand_fast<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n);
+    if (Bt->narrow) bfv_expand_narrow<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n);
+    else bfv_expand_fast<NS, NP, false>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n);
 }
 template <int NS, int NP>
 __global__ __launch_bounds__(256) void k_bfv_contract_fast(const u64* __restrict__ src, u64* __restrict__ dst,
@@ -425,5 +789,6 @@ __global__ __launch_bounds__(256) void k_bfv_contract_fast(const u64* __restrict
     const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
     const size_t p = blockIdx.x / gx;
     if (k >= n) return;
-    bfv_contract_fast<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
+    if (Bt->narrow) bfv_contract_narrow<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
+    else bfv_contract_fast<NS, NP, false>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
 }

@@ -96,6 +96,29 @@ TFHE_HD void acc_mac(acc128& a, u64 x, u64 y) {
     a.lo = s;
 }
 
+// Sums of products of operands below 2^52, both split into 26-bit halves: the four partial products accumulate in three
+// independent u64 lanes with ONE v_mad_u64_u32 each and no carry chain (up to 16 terms: lane s1 stays below 2^57).
+struct acc52 {
+    u64 s0, s1, s2;  // value = s0 + s1 2^26 + s2 2^52
+};
+TFHE_HD void acc52_mac(acc52& a, u32 x0, u32 x1, u32 c0, u32 c1) {
+    a.s0 += (u64)x0 * c0;
+    a.s1 += (u64)x0 * c1;
+    a.s1 += (u64)x1 * c0;
+    a.s2 += (u64)x1 * c1;
+}
+TFHE_HD void acc52_fold(const acc52& a, u64& lo, u64& hi) {
+    u64 l = a.s0, h = 0;
+    u64 t = a.s1 << 26;
+    l += t;
+    h += (a.s1 >> 38) + (l < t);
+    t = a.s2 << 52;
+    l += t;
+    h += (a.s2 >> 12) + (l < t);
+    lo = l;
+    hi = h;
+}
+
 // bit reversal of the low `bits` bits
 TFHE_HD u32 brev_bits(u32 x, int bits) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -110,6 +110,13 @@ struct ntt_limb_t {   // per-limb constants (device copy lives in the context)
     const ftwd_t* Wdbs;
 };
 
+// Progress hook of the butterfly loops: called after every twiddle group with the number of butterflies of the
+// pass done before / after it and the pass total.  The staged kernels use it to spread memory instructions
+// (LDS-DMA of the next row, stores of the previous one) through the arithmetic instead of issuing them in a clump.
+struct no_hook {
+    TFHE_HD void operator()(int, int, int) const {}
+};
+
 // digit lift of the RNS key-switch decomposition (see ntt_io_t below)
 struct lift_t {
     u64 qi, half, qj;
@@ -211,11 +218,17 @@ struct ArithFp {
     static TFHE_HD tw ld_inv_b(const ctx& c, u32 i) { return ld(c.Winvb, i); }
     static TFHE_HD bool has_b(const ctx& c) { return c.Wb != nullptr; }
     static TFHE_HD void bf_fwd(elem& x, elem& y, tw w, const ctx& c) {
+#ifdef TFHE_ABL_NOALU
+        x += w.w; return;
+#endif
         const double t = fp_mulmod_c(y, w, c.p, c.pinv);
         y = x - t;
         x = x + t;
     }
     static TFHE_HD void bf_inv(elem& x, elem& y, tw w, const ctx& c) {
+#ifdef TFHE_ABL_NOALU
+        x += w.w; return;
+#endif
         const double a = x + y, d = x - y;
         x = a;
         y = fp_mulmod_c(d, w, c.p, c.pinv);
@@ -269,7 +282,12 @@ struct pgeom {
         c0 = (u32)u * T + tid;
         const u32 c = BREV ? brev_bits(c0, LOGB - K) : c0;
         const u32 lo = c & ((1u << LO) - 1);
+        // one register set and LO >= LOGT: c = tid < 2^LO, so the twiddle index is workgroup-uniform (scalar loads)
+#ifdef TFHE_NO_UNIFORM_HI
         hi = c >> LO;
+#else
+        hi = (!BREV && SETS == 1 && LO >= LOGT) ? 0u : c >> LO;
+#endif
         base = (hi << (LOGB - S0)) + lo;
     }
 };
@@ -288,7 +306,9 @@ TFHE_HD void fwd_load_tw(typename A::tw* tw, const typename A::ctx& C, u32 tid, 
         for (int d = D0; d < D1; d++)
 #pragma unroll
             for (int g = 0; g < (1 << d); g++)
-                tw[u * G::NTW + (1 << d) - 1 + g] = A::ld_fwd(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
+                tw[u * G::NTW + (1 << d) - 1 + g] = (LAST && pre == 1u && A::has_b(C))
+                                                        ? A::ld_fwd_b(C, (1u << (S0 + d)) + (c0 << d) + (u32)g)
+                                                        : A::ld_fwd(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
     }
 }
 // raw 64-bit words of the operands (global: residues; LDS: the policy's element bits)
@@ -307,13 +327,17 @@ TFHE_HD void fwd_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, c
             raw[u * G::R + r] = FIRST ? gsrc[j] : lds[pb + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)];
         }
     }
+#ifndef TFHE_NO_LOADFENCE
+    TFHE_SCHED_FENCE();  // every operand is requested before the first butterfly (no just-in-time read/wait pairs)
+#endif
     (void)lift;
 }
 // Butterflies of the pass.  Twiddles of stages d < PF come from `twp` (requested ahead by the caller);
 // the others are loaded here (the compiler schedules those loads).
-template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int PF, int USEL = -1, bool SPLIT = false>
+template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int PF, int USEL = -1, bool SPLIT = false,
+          class HOOK = no_hook>
 TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
-                         u32 pre, const lift_t* lift = nullptr, const u64* raw_hi = nullptr) {
+                         u32 pre, const lift_t* lift = nullptr, const u64* raw_hi = nullptr, const HOOK& hook = HOOK()) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
     // permuted boundary table: whole-transform blocks (pre == 1) or the halves of a split transform (pre = 2 + sb,
     // with the split-permuted copy in C.Wb)
@@ -354,6 +378,7 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
                     const int r0 = (g << (K - d)) + i;
                     A::bf_fwd(vv[r0], vv[r0 + half], w, C);
                 }
+                hook(((u * K + d) * (G::R / 2)) + g * half, ((u * K + d) * (G::R / 2)) + (g + 1) * half, G::SETS * K * (G::R / 2));
             }
             if (K >= 5 && d == 2) {  // range control inside 5-stage passes (fp64 budget; no-op for u64)
 #pragma unroll
@@ -429,11 +454,14 @@ TFHE_HD void inv_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, i
             }
         }
     }
+#ifndef TFHE_NO_LOADFENCE
+    TFHE_SCHED_FENCE();
+#endif
 }
 // Inverse butterflies (stage K-1 first).  Stages d >= K-PF come from `twp`; the others are loaded here.
-template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE, int PF, int USEL = -1>
+template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE, int PF, int USEL = -1, class HOOK = no_hook>
 TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
-                         u32 pre) {
+                         u32 pre, const HOOK& hook = HOOK()) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
     const bool use_b = FROM_GLOBAL && pre == 1u && A::has_b(C);
 #pragma unroll
@@ -463,6 +491,8 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
                         A::bf_inv(vv[r0], vv[r0 + half], w, C);
                     }
                 }
+                hook(((u * K + (K - 1 - d)) * (G::R / 2)) + g * half, ((u * K + (K - 1 - d)) * (G::R / 2)) + (g + 1) * half,
+                     G::SETS * K * (G::R / 2));
             }
             // range control after every third processed stage (pass ends are handled by the store): sums double per
             // stage, 1/2 -> 4 over three stages, products stay <= 2.2 (fp64arith.h)
