@@ -126,6 +126,45 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_block(const u64* __restri
                                            (1u << x) + sb, x, brev_bits(sb, x), lift);
     }
 }
+// Digit-lift forward transforms of the key switch (ntt_io_t mode 1) with the source row read ONCE: item = (ciphertext b,
+// digit i); the residues of limb i of c[end] stay in registers while the workgroup lifts them into each of the nw working
+// limbs j in turn and transforms (rows (b*level + i)*nw + j of dst).  Whole-transform blocks only (x == 0).
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_lift(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems,
+                                                             ntt_io_t io) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0);
+    typedef pgeom<LOGB, LOGT, 0, K1> G1;
+    const u32 tid = threadIdx.x;
+    bool first = true;
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const u32 b = item / io.level, i = item % io.level;
+        const u64* grow = src + ((size_t)((b * io.polys + io.polys - 1) * io.level + i) << LOGB);
+        u64 raw[G1::E];
+        fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, grow, tid);
+        lift_t lf;
+        lf.qi = LT[sel.idx[i]].q;
+        lf.half = lf.qi >> 1;
+        for (u32 j = 0; j < io.nw; j++) {
+            const ntt_limb_t& Lj = LT[sel.idx[j]];
+            lf.qj = Lj.q;
+            lf.bj = Lj.br;
+            const typename A::ctx C = A::make(Lj);
+            u64* gdst = dst + ((size_t)(item * io.nw + j) << LOGB);
+            if (!first) __syncthreads();  // the previous transform's last pass has read LDS
+            first = false;
+            {
+                typename A::elem v[G1::E];
+                fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u, &lf);
+                fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+            }
+            __syncthreads();
+            fwd_schedule<A, LOGB, LOGT, K1>(lds, nullptr, gdst, C, tid, 1u, 0, 0u, nullptr);
+        }
+    }
+}
+
 template <class A, int LOGB, int LOGT, int IOMODE>
 __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restrict__ src, u64* __restrict__ dst,
                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
@@ -696,6 +735,68 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
             if (pend) {
                 r1 = addmod(r1, barrett_reduce128(s1.lo, s1.hi, L.br), L.q);
                 r2 = addmod(r2, barrett_reduce128(s2.lo, s2.hi, L.br), L.q);
+            }
+            *s1p = r1;
+            *s2p = r2;
+        }
+    }
+}
+
+// Same sums for working moduli below 2^52, two coefficients per thread (16-byte loads / stores) and carry-free
+// 26-bit-split accumulation (modarith.h acc52): the kernel is bound by the digit stream, not by the multiplier.
+typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+template <int DCH>
+__global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk, const u64* __restrict__ dig,
+                                                      u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
+                                                      int Lk, u32 n, u32 batch, u32 bsplit) {
+    static_assert(DCH + 1 <= 16, "acc52 term budget");
+    const u32 gx = (n / 2 + 255) / 256, tile = blockIdx.x % gx, j = (blockIdx.x / gx) % (u32)A.nw, slice = blockIdx.x / (gx * (u32)A.nw);
+    const u32 k = (tile * 256 + threadIdx.x) * 2;
+    const u32 per = (batch + bsplit - 1) / bsplit, b_lo = slice * per, b_hi = b_lo + per < batch ? b_lo + per : batch;
+    if (k >= n) return;
+    const barrett_t br = LT[A.w.idx[j]].br;
+    for (int i0 = 0; i0 < A.level; i0 += DCH) {
+        u32 mk0[DCH][2], mk1[DCH][2], md0[DCH][2], md1[DCH][2];
+#pragma unroll
+        for (int ii = 0; ii < DCH; ii++) {
+            const int i = i0 + ii < A.level ? i0 + ii : A.level - 1;
+            const u64x2_t a = *(const u64x2_t*)(evk + (((size_t)i * 2 + 0) * Lk + A.w.idx[j]) * n + k);
+            const u64x2_t d = *(const u64x2_t*)(evk + (((size_t)i * 2 + 1) * Lk + A.w.idx[j]) * n + k);
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                mk0[ii][v] = (u32)a[v] & 0x3ffffffu; mk1[ii][v] = (u32)(a[v] >> 26);
+                md0[ii][v] = (u32)d[v] & 0x3ffffffu; md1[ii][v] = (u32)(d[v] >> 26);
+            }
+        }
+        for (u32 b = b_lo; b < b_hi; b++) {
+            u64x2_t* s1p = (u64x2_t*)(S + (((size_t)b * 2 + 0) * A.nw + j) * n + k);
+            u64x2_t* s2p = (u64x2_t*)(S + (((size_t)b * 2 + 1) * A.nw + j) * n + k);
+            u64x2_t p1 = {0, 0}, p2 = {0, 0};
+            if (i0) { p1 = *s1p; p2 = *s2p; }
+            acc52 s1[2] = {{p1[0], 0, 0}, {p1[1], 0, 0}}, s2[2] = {{p2[0], 0, 0}, {p2[1], 0, 0}};
+            u64x2_t dv[DCH];
+#pragma unroll
+            for (int ii = 0; ii < DCH; ii++)
+                if (i0 + ii < A.level) dv[ii] = *(const u64x2_t*)(dig + (((size_t)b * A.level + i0 + ii) * A.nw + j) * n + k);
+#pragma unroll
+            for (int ii = 0; ii < DCH; ii++) {
+                if (i0 + ii < A.level) {
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        const u32 d0 = (u32)dv[ii][v] & 0x3ffffffu, d1 = (u32)(dv[ii][v] >> 26);
+                        acc52_mac(s1[v], d0, d1, md0[ii][v], md1[ii][v]);
+                        acc52_mac(s2[v], d0, d1, mk0[ii][v], mk1[ii][v]);
+                    }
+                }
+            }
+            u64x2_t r1, r2;
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                u64 lo, hi;
+                acc52_fold(s1[v], lo, hi);
+                r1[v] = barrett_reduce128(lo, hi, br);
+                acc52_fold(s2[v], lo, hi);
+                r2[v] = barrett_reduce128(lo, hi, br);
             }
             *s1p = r1;
             *s2p = r2;

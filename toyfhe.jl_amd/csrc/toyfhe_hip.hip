@@ -129,6 +129,22 @@ int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const 
     }
     constexpr int LOGT = logt_for(LOGB);
     const size_t lds = (size_t)lds_words<LOGB, LOGT>() * 8;
+    if constexpr (IOMODE == 1) {
+        // digit lift, whole-transform blocks: read each source row once and produce all nw lifted transforms from it
+        if (x == 0 && c->variant != 3 && io.nw >= 2 && rows % io.nw == 0) {
+            auto lkern = k_ntt_fwd_lift<A, LOGB, LOGT>;
+            static bool lattr_set = false;
+            if (!lattr_set) { int rc = set_lds(lkern, lds); if (rc) return rc; lattr_set = true; }
+            const unsigned litems = (unsigned)(rows / io.nw);
+            const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(160 * 1024) / lds, (size_t)2048 >> LOGT}));
+            const unsigned lgrid = std::min(litems, (unsigned)c->num_cus * per_cu);
+            prof_begin(c, rows);
+            hipLaunchKernelGGL(lkern, dim3(lgrid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, litems, io);
+            prof_end(c);
+            HIP_TRY(hipGetLastError());
+            return TFHE_OK;
+        }
+    }
     if constexpr (std::is_same<A, ArithFp>::value && LOGB == 14) {
         // whole 2^14 rows in fp64: the staged kernel (next row copied HBM -> LDS under the last pass)
         if (x == 0 && c->variant == 4) {  // forward: the staged kernel measures slower than the plain one; kept as a cross-check path
@@ -547,7 +563,15 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
     const unsigned gx = (n + 255) / 256;
     // enough workgroups to fill the chip: split the batch into slices (the key is re-read once per slice)
     const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx - 1) / (nw * gx)));
-    hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit);
+    bool narrow = (n % 2 == 0);
+    for (int j = 0; j < nw; j++) narrow = narrow && (c->limbs_host[A.w.idx[j]].q >> 52) == 0;
+    if (narrow) {
+        const unsigned gx2 = (n / 2 + 255) / 256;
+        const unsigned bs2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx2 - 1) / (nw * gx2)));
+        hipLaunchKernelGGL(k_ks_inner_n2<8>, dim3((unsigned)nw * gx2 * bs2), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2);
+    } else {
+        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit);
+    }
     HIP_TRY(hipGetLastError());
     if (special) {
         rc = run_ntt(c, true, S, S, batch * 2 * nw, A.w);
