@@ -43,11 +43,51 @@ def test_nntt_inntt_match_oracle(logn, bits, nq):
     ctx = tf.Context(N, qs)
     assert ctx.psis == ref.psis
     want = ref.nntt(a)
-    for variant in ((0, 1) if logn >= 10 else (0,)):
+    for variant in ((0, 1, 2, 3) if logn >= 10 else (0,)):   # 1-3: cross-check kernel families (include/toyfhe_hip.h)
         ctx.set_ntt_variant(variant)
         got = run_ntt(ctx, a)
         assert np.array_equal(got, want), (logn, bits, variant)
         assert np.array_equal(run_ntt(ctx, want, inverse=True), a), (logn, bits, variant)
+
+
+@pytest.mark.parametrize("rows", [1, 255, 3 * 256 + 17])
+def test_nntt_many_rows_per_workgroup(rows):
+    """N = 2^14 with more rows than compute units: every workgroup walks several rows, which is where the staged
+    inverse kernel copies the next row into LDS underneath the last pass (and where the tail of the walk is ragged)."""
+    N = 1 << 14
+    qs = H.chain(50, 3, N)
+    rng = np.random.default_rng(rows)
+    ref1, ref3 = ref_cpu.RefCtx(N, qs[:1]), ref_cpu.RefCtx(N, qs)
+    ctx = tf.Context(N, qs)
+    a = H.rand_residues(rng, qs[:1], (rows,), N)                    # rows x 1 limb, all on modulus 0
+    want = ref1.nntt(a)
+    for variant in (0, 3):
+        ctx.set_ntt_variant(variant)
+        assert np.array_equal(run_ntt(ctx, a, idx=[0]), want), variant
+        assert np.array_equal(run_ntt(ctx, want, inverse=True, idx=[0]), a), variant
+    ctx.set_ntt_variant(0)
+    if rows >= 3:                                                   # rows cycling through three moduli
+        b = H.rand_residues(rng, qs, (rows // 3,), N)
+        wantb = ref3.nntt(b)
+        assert np.array_equal(run_ntt(ctx, b), wantb)
+        assert np.array_equal(run_ntt(ctx, wantb, inverse=True), b)
+
+
+def test_keyswitch_more_digit_rows_than_compute_units():
+    """Key switch at N = 2^14 with batch * level > 256: the read-once digit-lift kernel and the staged inverse
+    (addend mode) both walk several items per workgroup."""
+    N, Lk, level, batch = 1 << 14, 3, 3, 90
+    qs = H.chain(50, Lk, N)
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(90)
+    evk = H.uniform_evk(rng, qs, Lk, N)
+    ct = H.rand_residues(rng, qs, (batch, 2), N)
+    devk, dct, dout = dev(evk), dev(ct), tf.DeviceBuffer(batch * 2 * level * N)
+    want = ref.keyswitch(level, False, evk, ct)
+    for variant in (0, 3):
+        ctx.set_ntt_variant(variant)
+        ctx.keyswitch(Lk, level, False, devk.ptr, Lk, dct.ptr, 2, dout.ptr, batch)
+        assert np.array_equal(dout.to_numpy(want.shape), want), variant
 
 
 @pytest.mark.parametrize("logn", [15, 16])

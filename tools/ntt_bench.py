@@ -23,7 +23,7 @@ def timed(f):
     ctx.sync()
     return (time.perf_counter() - t) / reps
 
-variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 3, 4]
+variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 3]
 for rnd in range(3):                   # interleaved rounds: order effects show up as round-to-round spread
     print("round %d  copy %7.0f GB/s" % (rnd, gb / timed(lambda: ctx.select_limbs(a.ptr, b.ptr, count, L, list(range(L))))))
     for v in variants:

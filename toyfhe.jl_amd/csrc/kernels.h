@@ -263,51 +263,6 @@ struct row_stager {
         }
     }
 };
-// finished residues of the previous item, written out piecewise underneath the first pass of the current one
-template <int LOGB, int LOGT, int K3>
-struct fwd_out_storer {  // forward: natural-order positions of the bit-reversed last-pass map (fwd_store, LAST)
-    const u64* o;
-    u64* g;
-    u32 tid;
-    __device__ __forceinline__ void one(int i) const {
-        constexpr int R3 = 1 << K3;
-        const u32 c0 = (u32)(i / R3) * (1u << LOGT) + tid;
-#ifdef TFHE_ABL_NOMEM
-        asm volatile("" ::"v"(o[i]), "v"(c0));
-        return;
-#endif
-        g[(brev_bits((u32)(i % R3), K3) << (LOGB - K3)) + c0] = o[i];
-    }
-    __device__ __forceinline__ void operator()(int before, int after, int total) const {
-        constexpr int E = 1 << (LOGB - LOGT);
-        const int lo = E * before / total, hi = E * after / total;
-        if (hi > lo && g) {
-#pragma unroll
-            for (int i = lo; i < hi; i++) one(i);
-        }
-    }
-};
-template <int LOGB, int LOGT>
-struct inv_out_storer {  // inverse: element r of thread tid is coefficient tid + r 2^LOGT
-    const u64* o;
-    u64* g;
-    u32 tid;
-    __device__ __forceinline__ void one(int i) const {
-#ifdef TFHE_ABL_NOMEM
-        asm volatile("" ::"v"(o[i]));
-        return;
-#endif
-        g[tid + ((u32)i << LOGT)] = o[i];
-    }
-    __device__ __forceinline__ void operator()(int before, int after, int total) const {
-        constexpr int E = 1 << (LOGB - LOGT);
-        const int lo = E * before / total, hi = E * after / total;
-        if (hi > lo && g) {
-#pragma unroll
-            for (int i = lo; i < hi; i++) one(i);
-        }
-    }
-};
 template <class T>
 __device__ __forceinline__ void pin_vgpr(T& x) { asm volatile("" : "+v"(x)); }
 
@@ -336,85 +291,6 @@ __device__ __forceinline__ item_rows_t item_rows(u32 pl, const limb_sel_t& sel, 
         r.arow = g * io.add_gstride + w;
     }
     return r;
-}
-
-template <class A, int LOGB, int LOGT, int IOMODE>
-__global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_staged(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel,
-                                                               u32 nitems, ntt_io_t io) {
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
-    static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass schedule expected");
-    typedef pgeom<LOGB, LOGT, K1 + K2, K3> G3;
-    constexpr int E = G3::E;
-    const u32 tid = threadIdx.x;
-    u32 item = blockIdx.x;
-    if (item >= nitems) return;
-    lift_t lf;
-    item_rows_t R = item_rows<IOMODE>(item, sel, io, lf, LT);
-    row_stager<LOGB, LOGT>(lds, src + ((size_t)R.srow << LOGB), tid, true).all();
-    TFHE_WAIT_VM0();
-    u32 itc = 0;
-    (void)itc;
-    u64 o[E];             // finished residues of the previous item ...
-    u64* gprev = nullptr; // ... and where they go: stored underneath pass 1 of the next item
-    for (;;) {
-        const typename A::ctx C = A::make(LT[sel.idx[R.j]]);
-        u64* gdst = dst + ((size_t)R.drow << LOGB);
-        __syncthreads();  // the staged row (every wave's pieces) is in LDS
-        TFHE_STAMP(0);
-        {
-            u64 raw[E];
-            typename A::elem v[E];
-            fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, lds, tid);
-            const fwd_out_storer<LOGB, LOGT, K3> storer{o, gprev, tid};
-            fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0, -1, false, fwd_out_storer<LOGB, LOGT, K3>>(
-                v, raw, nullptr, C, tid, 1u, IOMODE == 1 ? &lf : nullptr, nullptr, storer);
-            __syncthreads();  // every thread has taken its operands out of the staged image
-            TFHE_STAMP(1);
-            fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
-        }
-        __syncthreads();
-        TFHE_STAMP(2);
-        typename A::tw tw3[G3::SETS * G3::NTW];
-        fwd_load_tw<A, LOGB, LOGT, K1 + K2, K3, true>(tw3, C, tid, 1u);  // requested early, needed after pass 2
-        ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
-        __syncthreads();
-        TFHE_STAMP(3);
-        const u32 next = item + gridDim.x;
-        {
-            u64 raw[E];
-            typename A::elem v[E];
-            fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(raw, lds, nullptr, tid);
-#pragma unroll
-            for (int i = 0; i < G3::SETS * G3::NTW; i++) pin_vgpr(tw3[i].w);  // twiddles have landed (vmcnt) ...
-#pragma unroll
-            for (int i = 0; i < E; i++) pin_vgpr(raw[i]);                     // ... and so have the operands (lgkmcnt)
-            __syncthreads();  // LDS is free
-            TFHE_STAMP(4);
-            item_rows_t Rn = R;
-            lift_t lfn = lf;
-            if (next < nitems) Rn = item_rows<IOMODE>(next, sel, io, lfn, LT);
-            const row_stager<LOGB, LOGT> stager(lds, src + ((size_t)Rn.srow << LOGB), tid, next < nitems);
-            fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, K3, -1, false, row_stager<LOGB, LOGT>>(v, raw, tw3, C, tid, 1u, nullptr,
-                                                                                                    nullptr, stager);
-#pragma unroll
-            for (int i = 0; i < E; i++) o[i] = A::out_fwd(v[i], C);
-            TFHE_SCHED_FENCE();
-            TFHE_STAMP(6);
-            TFHE_WAIT_VM0();  // own pieces of the next row are in LDS
-            TFHE_STAMP(7);
-            gprev = gdst;
-            R = Rn;
-            lf = lfn;
-        }
-        if (next >= nitems) break;
-        item = next;
-        itc++;
-    }
-    const fwd_out_storer<LOGB, LOGT, K3> last{o, gprev, tid};
-#pragma unroll
-    for (int i = 0; i < E; i++) last.one(i);
 }
 
 template <class A, int LOGB, int LOGT, int IOMODE>

@@ -145,20 +145,6 @@ int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const 
             return TFHE_OK;
         }
     }
-    if constexpr (std::is_same<A, ArithFp>::value && LOGB == 14) {
-        // whole 2^14 rows in fp64: the staged kernel (next row copied HBM -> LDS under the last pass)
-        if (x == 0 && c->variant == 4) {  // forward: the staged kernel measures slower than the plain one; kept as a cross-check path
-            auto skern = k_ntt_fwd_staged<A, LOGB, LOGT, IOMODE>;
-            static bool sattr_set = false;
-            if (!sattr_set) { int rc = set_lds(skern, lds); if (rc) return rc; sattr_set = true; }
-            const unsigned sgrid = std::min((unsigned)rows, (unsigned)c->num_cus);
-            prof_begin(c, rows);
-            hipLaunchKernelGGL(skern, dim3(sgrid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows, io);
-            prof_end(c);
-            HIP_TRY(hipGetLastError());
-            return TFHE_OK;
-        }
-    }
     auto kern = k_ntt_fwd_block<A, LOGB, LOGT, IOMODE>;
     static bool attr_set = false;
     if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
@@ -407,7 +393,7 @@ int tfhe_ctx_sync(tfhe_ctx* c) {
     return TFHE_OK;
 }
 int tfhe_ctx_set_ntt_variant(tfhe_ctx* c, int v) {
-    if (!c || v < 0 || v > 4) return fail(TFHE_E_BADARG, "variant must be 0..4");
+    if (!c || v < 0 || v > 3) return fail(TFHE_E_BADARG, "variant must be 0, 1, 2 or 3");
     c->variant = v;
     return TFHE_OK;
 }
