@@ -95,6 +95,15 @@ def main():
     value = total_units / elapsed
     ntt_bytes = limb_polys * 2 * N * 8                   # one read + one write per limb transform
     achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs, gfx950 corrections;
+    # tools/pmc_probe.py + tools/pmc_summarize.py).  bench.py cannot run the counters itself, so it applies the committed
+    # per-limb-NTT figures to this run's launch sizes: 132 forward and 67 inverse limb transforms per ciphertext-mul.
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_ntt_traffic.json")
+    if os.path.exists(pmc_path) and launches:
+        pmc = json.load(open(pmc_path))
+        per_ntt = (132 * pmc["fwd"]["hbm_bytes_per_limb_ntt"] + 67 * pmc["inv"]["hbm_bytes_per_limb_ntt"]) / 199.0
+        traffic = per_ntt * limb_polys / launches
     result = {
         "metric": "ciphertext-mul/s (BFV ct*ct + relinearize, N=2^14, L=8 RNS)",
         "value": value,
@@ -111,9 +120,13 @@ def main():
         "config": {"workload": "BFV N=2^14, L=8 RNS limbs (50-bit primes), extension basis 17 limbs, t=65537, "
                                "ciphertext-mul + relinearize (RNS-digit keyswitch), bit-exact", "batch_per_gpu": B,
                    "global_batch": B * world, "sharding": f"batch x{world}, no data-path collective"},
-        "roofline": {"bound": "hbm", "kernel": "k_ntt_{fwd,inv}_block<14,10> (negacyclic NTT, one limb per workgroup)",
+        "roofline": {"bound": "hbm", "kernel": "2^14-point negacyclic NTT kernels (k_ntt_fwd_block / k_ntt_fwd_lift / k_ntt_inv_staged, "
+                               "fp64 butterflies, one limb row per workgroup pass)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "launches": launches, "limb_ntts": limb_polys,
+                     "traffic": traffic, "traffic_unit": "bytes per launch (PMC bytes per limb-NTT from profiles/r01_pmc_ntt_traffic.json "
+                                                         "x limb-NTTs per launch)",
+                     "algorithmic_bytes_per_launch": ntt_bytes / launches if launches else None,
+                     "launches": launches, "limb_ntts": limb_polys,
                      "avg_launch_ms": ntt_ms / launches if launches else None,
                      "ntt_share_of_step": ntt_ms * 1e-3 / elapsed if elapsed > 0 else None},
     }
