@@ -115,6 +115,16 @@ int tfhe_keyswitch(tfhe_ctx *ctx, int key_limbs, int level, int special, const u
 /* rotate(gk, c) = keyswitch(gk, apply_galois_element(c, g)) (rlwe_she.jl:355-359) */
 int tfhe_rotate(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint64_t *evk, int n_digits, uint64_t galois_element, const uint64_t *ct, uint64_t *out, int64_t batch);
 
+/* ---- K14: keyswitch with base-2^w digits (relin_window = w != 0, rlwe_she.jl:330-338; the default for
+ * single-modulus rings, rlwe_she.jl:271) -------------------------------------------------------------
+ * The ring is limbs 0..level-1 of ctx (no special prime).  Digit i of a coefficient is digit i of
+ * convert(Integer, x) in [0, Q) -- reconstructed exactly from the residues when level > 1 -- embedded in every
+ * limb; out_s = c_s + sum_i key_i,s * digit_i.
+ *   evk: [n_windows][2][level][N], component 0 = mask, 1 = masked, NTT domain; n_windows must equal
+ *        ndigits(Q, base = 2^w) = ceil(bitlength(Q) / w) (rlwe_she.jl:282,333), else TFHE_E_PARAMS_MISMATCH.
+ *   window_bits: 1..32 with 2^w below every modulus.   ct / out as tfhe_keyswitch. */
+int tfhe_keyswitch_window(tfhe_ctx *ctx, int level, int window_bits, const uint64_t *evk, int n_windows, const uint64_t *ct, int polys, uint64_t *out, int64_t batch);
+
 /* ---- K12/K13: BFV multiplication (rlwe_she.jl:247-262 with bfv.jl:34-40,172-226) ---------------
  * plan = (ℛ = small ctx limbs idx_s, ℛbig = big ctx limbs idx_b, t).  Supported basis relations:
  * ℛbig ⊇ ℛ as sets of primes, or disjoint (test/bfv_crt.jl); anything else TFHE_E_UNSUPPORTED.

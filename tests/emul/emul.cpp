@@ -139,6 +139,17 @@ long emul_conv(const uint64_t* a, int k, const uint64_t* t, int m, int centred, 
     return g_slow_hits;
 }
 
+// base-2^w digits of `count` coefficients: res [count][k] -> out [count][nwin] (conv_core.h window_digits_coeff)
+void emul_window_digits(const uint64_t* a, int k, int wbits, int nwin, const uint64_t* res, uint64_t* out, long count) {
+    conv_host_t H;
+    build_conv_host(std::vector<u64>(a, a + k), std::vector<u64>(), &H);
+    std::vector<u64> d((size_t)nwin * k);
+    for (long c = 0; c < count; c++) {
+        window_digits_coeff(k > 1 ? &H.tab : nullptr, res + c * k, 1, k, wbits, nwin, d.data(), (size_t)k, 1);
+        for (int i = 0; i < nwin; i++) out[c * nwin + i] = d[(size_t)i * k + (k - 1)];  // every limb holds the same digit
+    }
+}
+
 // BFV expand / contract on [count][limbs][N] buffers; returns 0 or the table-construction error code
 int emul_bfv(const uint64_t* qs, int ns, const uint64_t* pb, int nb, uint64_t t, int contract, int64_t N,
              const uint64_t* src, uint64_t* dst, long count, long* slow_hits) {

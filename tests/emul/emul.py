@@ -18,6 +18,8 @@ def lib():
         L.emul_ntt.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, u64p, u64p]
         L.emul_conv.restype = C.c_long
         L.emul_conv.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_int, u64p, u64p, C.c_long]
+        L.emul_window_digits.argtypes = [u64p, C.c_int, C.c_int, C.c_int, u64p, u64p, C.c_long]
+        L.emul_window_digits.restype = None
         L.emul_bfv.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_uint64, C.c_int, C.c_int64, u64p, u64p, C.c_long,
                                C.POINTER(C.c_long)]
         L.emul_bfv_fast.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_uint64, C.c_int, C.c_int64, u64p, u64p, C.c_long]
@@ -44,6 +46,15 @@ def conv(a, t, res, centred):
     out = np.empty((res.shape[0], len(t)), dtype=np.uint64)
     slow = lib().emul_conv(_p(a), len(a), _p(t), len(t), int(centred), _p(res), _p(out), res.shape[0])
     return out, slow
+
+
+def window_digits(a, wbits, nwin, res):
+    """digits [count][nwin] of the integers with residues res [count][k] over the basis a"""
+    a_ = np.array(a, dtype=np.uint64)
+    res = np.ascontiguousarray(res, dtype=np.uint64)
+    out = np.empty((res.shape[0], nwin), dtype=np.uint64)
+    lib().emul_window_digits(_p(a_), len(a), int(wbits), int(nwin), _p(res), _p(out), res.shape[0])
+    return out
 
 
 def bfv(qs, pb, t, src, N, contract):

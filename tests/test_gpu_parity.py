@@ -243,6 +243,40 @@ def test_keyswitch_matches_oracle(N, bits, Lk, special):
         ctx.keyswitch(Lk, Lk + 1, special, devk.ptr, Lk, devk.ptr, 2, devk.ptr, 1)  # level outside the key ring
 
 
+@pytest.mark.parametrize("N,bits,L,w", [(32, 60, 1, 1), (64, 50, 1, 8), (32, 40, 2, 10), (2048, 50, 3, 16), (16, 61, 4, 32),
+                                        (1 << 15, 50, 1, 20)])
+def test_keyswitch_window_matches_oracle(N, bits, L, w):
+    """K14: key switch with base-2^w digits of convert(Integer, x) (rlwe_she.jl:330-338), bit-exact against the spec
+    oracle; multi-limb rings need the exact integer reconstruction on the device."""
+    qs = H.chain(bits, L, N)
+    ring = spec.Ring(N, qs)
+    nwin = spec.ndigits(ring.Q, 2 ** w)
+    rng = np.random.default_rng(N + w)
+    ctx = tf.Context(N, qs)
+    batch = 1 if N > 4096 else 3
+    evk = np.stack([H.rand_residues(rng, qs, (2,), N) for _ in range(nwin)])          # [nwin][2][L][N], coefficient domain
+    evk_ntt = np.array([[spec.poly_nntt([list(map(int, l)) for l in comp], ring) for comp in pair] for pair in evk], dtype=np.uint64)
+    devk = dev(evk_ntt)
+    for polys in (2, 3):
+        ct = H.rand_residues(rng, qs, (batch, polys), N)
+        ct[0, polys - 1, :, 0] = 0                                                     # x = 0
+        ct[0, polys - 1, :, 1] = [q - 1 for q in qs]                                   # x = Q - 1
+        ct[0, polys - 1, :, 2] = 1                                                     # x = 1 (exact-alpha fallback)
+        dct, dout = dev(ct), tf.DeviceBuffer(batch * 2 * L * N)
+        ctx.keyswitch_window(L, w, devk.ptr, nwin, dct.ptr, polys, dout.ptr, batch)
+        got = dout.to_numpy((batch, 2, L, N))
+        for b in range(batch):
+            want = spec.keyswitch([([list(map(int, l)) for l in p[0]], [list(map(int, l)) for l in p[1]]) for p in evk],
+                                  [[list(map(int, l)) for l in c] for c in ct[b]], ring, ring, False, relin_window=w)
+            assert np.array_equal(got[b], np.array(want, dtype=np.uint64)), (polys, b)
+    with pytest.raises(tf.UsageError):
+        ctx.keyswitch_window(L, w, devk.ptr, nwin + 1, devk.ptr, 2, devk.ptr, 1)      # key / ring mismatch
+    with pytest.raises(AssertionError):
+        ctx.keyswitch_window(L, 33, devk.ptr, nwin, devk.ptr, 2, devk.ptr, 1)
+    with pytest.raises(AssertionError):
+        ctx.keyswitch_window(L, w, devk.ptr, nwin, devk.ptr, 4, devk.ptr, 1)           # rlwe_she.jl:318
+
+
 def test_golden_keyswitch_and_rotate():
     ctx = tf.Context(32, G["ksS_q"])
     devk, dct = dev(G["ksS_evk_ntt"]), dev(G["ksS_ct"])

@@ -77,6 +77,35 @@ def test_bfv_crt():
         c * tf.CipherText(other, c.cs)
 
 
+def test_bfv_keyswitch_window():
+    """test/bfv_keyswitch.jl:5-27 with the reference's default digit window (relin_window = 1, rlwe_she.jl:271):
+    single-modulus ciphertext ring, base-2 evaluation key with one component per bit of q."""
+    n = 1024
+    ch = chain(2**50 + 1, 4, n)
+    R, Rbig = tf.NegacyclicRing(n, ch[:1]), tf.NegacyclicRing(n, ch)
+    params = tf.BFVParams(R, Rbig, 7, 1, 3.2)
+    rng = np.random.default_rng(5)
+    kp1 = tf.keygen(rng, params)
+    ek = tf.keygen_evalmult(rng, kp1.priv)
+    assert len(ek.key.key) == ch[0].bit_length()                    # ndigits(q, base = 2)
+    c1 = tf.encrypt(rng, kp1, [2] + [0] * (n - 1))
+    assert tf.decrypt(kp1, c1)[0] == 2
+    sq = c1 * c1
+    assert tf.decrypt(kp1, sq)[0] == 4
+    sw = tf.keyswitch(ek, sq)
+    assert len(sw) == 2 and tf.decrypt(kp1, sw)[0] == 4
+    assert tf.decrypt(kp1, sw * c1)[0] == 1                         # 8 mod 7
+    # wider windows and a two-limb ring (exact integer reconstruction on the device)
+    R2 = tf.NegacyclicRing(n, ch[:2])
+    params2 = tf.BFVParams(R2, Rbig, 7, 11, 3.2)
+    kp2 = tf.keygen(rng, params2)
+    ek2 = tf.keygen_evalmult(rng, kp2.priv)
+    assert len(ek2.key.key) == -(-(ch[0] * ch[1]).bit_length() // 11)
+    c2 = tf.encrypt(rng, kp2, [3] + [0] * (n - 1))
+    sw2 = tf.keyswitch(ek2, c2 * c2)
+    assert len(sw2) == 2 and tf.decrypt(kp2, sw2)[0] == 2           # 9 mod 7
+
+
 def test_bfv_superset_extension_basis_batch():
     """the bench's basis relation (ℛbig ⊇ ℛ) on a batch of ciphertexts, slot-wise check of 6*7 etc."""
     n, t = 1024, 65537

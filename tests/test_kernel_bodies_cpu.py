@@ -198,3 +198,20 @@ def test_bfv_fast_path_bodies(bits, ns, np_):
             y[0, l, k] = (x * tinv) % big.Q % p
     assert np.array_equal(emul.bfv_fast(qs, pb, t, y, N, contract=True), ref_cpu.contract(cb, cs, t, y))
 
+
+
+@pytest.mark.parametrize("bits,k,w", [(60, 1, 1), (61, 1, 7), (50, 2, 10), (40, 3, 13), (61, 4, 32), (50, 8, 16)])
+def test_window_digit_bodies(bits, k, w):
+    """conv_core.h window_digits_coeff (the body of k_ks_window_digits): base-2^w digits of the exactly reconstructed
+    integer, against Python big integers (rlwe_she.jl:333-334: digits(convert(Integer, x), base = 2^w, pad = nwindows))."""
+    qs = _chain(bits, k, 64)
+    Q = 1
+    for q in qs:
+        Q *= q
+    nwin = -(-Q.bit_length() // w)
+    rng = random.Random(bits * 100 + k)
+    xs = [0, 1, Q - 1, Q // 2, Q // 2 + 1, (1 << (Q.bit_length() - 1)), (1 << 64) % Q, ((1 << 64) - 1) % Q] + [rng.randrange(Q) for _ in range(300)]
+    res = np.array([[x % q for q in qs] for x in xs], dtype=np.uint64)
+    got = emul.window_digits(qs, w, nwin, res)
+    want = np.array([[(x >> (i * w)) & ((1 << w) - 1) for i in range(nwin)] for x in xs], dtype=np.uint64)
+    assert np.array_equal(got, want)

@@ -99,6 +99,64 @@ TFHE_HD u32 conv_prepare(const conv_tab_t& T, u64* xi, int stride, bool centred)
     return carries + (borrow ? 0u : 1u);  // no final borrow  <=>  X >= (carries+1) A
 }
 
+// The exact plain lift itself, X - alpha A in [0, A), as T.nwords little-endian 64-bit words (xi, alpha from
+// conv_prepare(…, centred = false)).  Used where the reference takes digits of convert(Integer, x)
+// (rlwe_she.jl:334).  Word-serial: column sums of X in a 192-bit window, alpha A subtracted with a borrow chain.
+TFHE_HD void conv_words(const conv_tab_t& T, const u64* xi, int stride, u32 alpha, u64* out) {
+    u64 acc_lo = 0, acc_hi = 0, acc_ex = 0, mcarry = 0, borrow = 0;
+    for (int w = 0; w < T.nwords; w++) {
+        for (int j = 0; j < T.k; j++) {
+            const u64 xij = xi[(size_t)j * stride], mw = T.M[(size_t)j * T.nwords + w];
+            const u64 lo = xij * mw, hi = mulhi64(xij, mw);
+            u64 s = acc_lo + lo;
+            const u64 c = (s < lo);
+            acc_lo = s;
+            s = acc_hi + hi;
+            u64 c2 = (s < hi);
+            s += c;
+            c2 += (s < c);
+            acc_hi = s;
+            acc_ex += c2;
+        }
+        const u64 xw = acc_lo;  // word w of X
+        acc_lo = acc_hi; acc_hi = acc_ex; acc_ex = 0;
+        const u64 aw = T.Aw[w];
+        const u64 plo = aw * (u64)alpha, phi = mulhi64(aw, (u64)alpha);
+        const u64 yw = plo + mcarry;  // word w of alpha*A
+        mcarry = phi + (yw < plo);
+        const u64 d = xw - yw;
+        out[w] = d - borrow;
+        borrow = (u64)(xw < yw) | (u64)(d < borrow);
+    }
+}
+
+// Base-2^w digits of one coefficient (key switch with relin_window = w, rlwe_she.jl:333-337): digit i of
+// convert(Integer, x), x in [0, A) rebuilt exactly from the residues c[l*ls] (a single limb is its own integer);
+// digit i is written to d[i*ds_digit + l*ds_limb] for every limb l (the same small value in each).
+TFHE_HD void window_digits_coeff(const conv_tab_t* T, const u64* c, size_t ls, int level, int wbits, int nwin, u64* d,
+                                 size_t ds_digit, size_t ds_limb) {
+    u64 words[TFHE_MAX_LIMBS + 1];
+    int nwords = 1;
+    if (level == 1) {
+        words[0] = c[0];
+    } else {
+        u64 xi[TFHE_MAX_LIMBS];
+        for (int l = 0; l < level; l++) xi[l] = c[(size_t)l * ls];
+        const u32 alpha = conv_prepare(*T, xi, 1, false);
+        conv_words(*T, xi, 1, alpha, words);
+        nwords = T->nwords;
+    }
+    words[nwords] = 0;
+    const u64 mask = (1ull << wbits) - 1;
+    for (int i = 0; i < nwin; i++) {
+        const int bit = i * wbits, wd = bit >> 6, off = bit & 63;
+        u64 v = wd < nwords ? words[wd] >> off : 0;
+        if (off + wbits > 64 && wd + 1 < nwords) v |= words[wd + 1] << (64 - off);
+        v &= mask;
+        for (int l = 0; l < level; l++) d[(size_t)i * ds_digit + (size_t)l * ds_limb] = v;
+    }
+}
+
 // Step 2: the exact value (plain lift, or centred lift when `centred`) modulo target i.
 TFHE_HD u64 conv_eval(const conv_tab_t& T, const u64* xi, int stride, int i, u32 alpha, bool centred) {
     const barrett_t& bt = T.t[i];

@@ -692,6 +692,19 @@ __global__ __launch_bounds__(256) void k_ks_digits(const u64* __restrict__ ct, u
     u64* d = dig + (size_t)row * n;
     for (u32 k = threadIdx.x; k < n; k += blockDim.x) d[k] = lift_digit(c[k], lf);
 }
+// Base-2^w digits of the key switch (relin_window != 0, rlwe_she.jl:330-338): digit i of convert(Integer, x) for every
+// coefficient x of c[end], x in [0, Q) reconstructed exactly from its residues (conv_core.h; a single limb is its own
+// integer).  dig: [batch][nwin][level][N], the same small value in every limb.  One thread per coefficient.
+__global__ __launch_bounds__(256) void k_ks_window_digits(const u64* __restrict__ ct, u64* __restrict__ dig,
+                                                           const conv_tab_t* __restrict__ T, int level, int wbits, int nwin,
+                                                           int polys, u32 n, u32 gx) {
+    const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
+    const size_t b = blockIdx.x / gx;
+    if (k >= n) return;
+    window_digits_coeff(T, ct + ((b * polys + polys - 1) * level) * n + k, n, level, wbits, nwin,
+                        dig + (b * nwin * level) * n + k, (size_t)level * n, n);
+}
+
 // out[b][s][j] += c[b][s][j] for the components that have one (N > 2^14 path); rows = batch*2*level
 __global__ __launch_bounds__(256) void k_ks_add_ct(const u64* __restrict__ ct, u64* __restrict__ out,
                                                     const ntt_limb_t* __restrict__ LT, ks_arg_t A, u32 n, u32 add_s) {

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -61,6 +62,10 @@ struct tfhe_ctx {
     // profiling
     bool prof = false;
     std::vector<prof_pair> prof_pairs;
+    // exact-reconstruction tables of the window key switch, per level (built on first use)
+    std::map<int, conv_tab_t*> ksw_tabs;
+    std::vector<void*> ksw_allocs;
+    std::mutex ksw_mu;
 };
 
 namespace {
@@ -366,6 +371,7 @@ int tfhe_ctx_destroy(tfhe_ctx* c) {
     if (!c) return TFHE_OK;
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto* t : c->tabs) hipFree(t);
+    for (auto* t : c->ksw_allocs) hipFree(t);
     if (c->limbs_dev) hipFree(c->limbs_dev);
     if (c->ws) hipFree(c->ws);
     for (auto& p : c->prof_pairs) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -637,6 +643,103 @@ int tfhe_rotate(tfhe_ctx* c, int Lk, int level, int special, const uint64_t* evk
     if (rc) return rc;
     if ((g & 1) == 0) return fail(TFHE_E_BADARG, "galois element must be odd");
     return keyswitch_impl(c, Lk, level, special, evk, ct, 2, out, batch, g, true);
+}
+
+// ---- digit-window key switch (relin_window != 0, rlwe_she.jl:330-338) -----------------------------------------------
+static int ksw_table(tfhe_ctx* c, int level, const conv_tab_t** out) {
+    *out = nullptr;
+    if (level == 1) return TFHE_OK;
+    std::lock_guard<std::mutex> g(c->ksw_mu);
+    auto it = c->ksw_tabs.find(level);
+    if (it != c->ksw_tabs.end()) { *out = it->second; return TFHE_OK; }
+    conv_host_t H;
+    build_conv_host(std::vector<u64>(c->q.begin(), c->q.begin() + level), std::vector<u64>(), &H);
+    conv_tab_t T = H.tab;
+    auto up = [&](const std::vector<u64>& v, const u64** d) -> bool {
+        *d = nullptr;
+        if (v.empty()) return true;
+        void* p = nullptr;
+        if (hipMalloc(&p, v.size() * 8) != hipSuccess) return false;
+        c->ksw_allocs.push_back(p);
+        if (hipMemcpy(p, v.data(), v.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return false;
+        *d = (const u64*)p;
+        return true;
+    };
+    void* dt = nullptr;
+    if (!up(H.C, &T.C) || !up(H.M, &T.M) || !up(H.Aw, &T.Aw) || hipMalloc(&dt, sizeof T) != hipSuccess)
+        return fail(TFHE_E_NOMEM, "allocating the window-digit tables failed");
+    c->ksw_allocs.push_back(dt);
+    HIP_TRY(hipMemcpy(dt, &T, sizeof T, hipMemcpyHostToDevice));
+    c->ksw_tabs[level] = (conv_tab_t*)dt;
+    *out = (conv_tab_t*)dt;
+    return TFHE_OK;
+}
+
+int tfhe_keyswitch_window(tfhe_ctx* c, int level, int window_bits, const uint64_t* evk, int n_windows, const uint64_t* ct, int polys,
+                          uint64_t* out, int64_t batch) {
+    if (!c || !evk || !ct || !out) return fail(TFHE_E_BADARG, "null argument");
+    if (polys != 2 && polys != 3) return fail(TFHE_E_BADARG, "keyswitch needs a 2- or 3-element ciphertext (rlwe_she.jl:318), got %d", polys);
+    if (level < 1 || level > c->L) return fail(TFHE_E_LEVEL_MISMATCH, "level=%d outside [1,%d]", level, c->L);
+    if (batch < 0) return fail(TFHE_E_BADARG, "negative batch");
+    hostmath::bigint Q = hostmath::big_from(1);
+    u64 qmin = ~0ull;
+    for (int j = 0; j < level; j++) { Q = hostmath::big_mul_u64(Q, c->q[j]); qmin = std::min(qmin, c->q[j]); }
+    if (window_bits < 1 || window_bits > 32 || (qmin >> window_bits) == 0)
+        return fail(TFHE_E_BADARG, "window of %d bits: need 1 <= w <= 32 and 2^w below every modulus", window_bits);
+    int qbits = 0;
+    for (int w = (int)Q.size() - 1; w >= 0 && !qbits; w--)
+        if (Q[w]) qbits = w * 64 + hostmath::bitlen(Q[w]);
+    const int need = (qbits + window_bits - 1) / window_bits;  // ndigits(Q, base = 2^w), rlwe_she.jl:333
+    if (n_windows != need)
+        return fail(TFHE_E_PARAMS_MISMATCH, "evaluation key has %d components, a %d-bit modulus in %d-bit windows has %d digits", n_windows, qbits, window_bits, need);
+    if (batch == 0) return TFHE_OK;
+    const conv_tab_t* T = nullptr;
+    int rc = ksw_table(c, level, &T);
+    if (rc) return rc;
+    const size_t N = (size_t)c->N;
+    const u32 n = (u32)c->N;
+    const size_t per_ct = ((size_t)2 * level + (size_t)n_windows * level) * N * 8;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)128, (int64_t)((2048ull << 20) / per_ct)}));
+    const size_t ntt_tmp = c->logN > 14 ? (size_t)chunk * n_windows * level * N * 8 : 0;
+    void* ws = nullptr;
+    rc = ensure_ws(c, ntt_tmp + chunk * per_ct, &ws);
+    if (rc) return rc;
+    u64* S = (u64*)((char*)ws + ntt_tmp);
+    u64* dig = S + (size_t)chunk * 2 * level * N;
+    ks_arg_t A;   // inner product: `level` field = number of digits, nw = working limbs
+    memset(&A, 0, sizeof A);
+    A.level = n_windows; A.nw = level; A.special = 0; A.polys = polys;
+    A.w.n = level;
+    for (int j = 0; j < level; j++) A.w.idx[j] = j;
+    ks_arg_t Al = A;  // row bookkeeping of the add kernel: `level` = limbs
+    Al.level = level;
+    const u32 add_s = polys == 3 ? 2u : 1u;
+    const unsigned gx = (n + 255) / 256;
+    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int64_t nb = std::min(chunk, batch - b0);
+        const u64* cin = ct + (size_t)b0 * polys * level * N;
+        u64* cout = out + (size_t)b0 * 2 * level * N;
+        hipLaunchKernelGGL(k_ks_window_digits, dim3((unsigned)(nb * gx)), dim3(256), 0, c->stream, cin, dig, T, level, window_bits, n_windows, polys, n, gx);
+        HIP_TRY(hipGetLastError());
+        rc = run_ntt(c, false, dig, dig, nb * n_windows * level, A.w);
+        if (rc) return rc;
+        const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nb, (4096 + level * gx - 1) / (level * gx)));
+        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)level * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, level, n, (u32)nb, bsplit);
+        HIP_TRY(hipGetLastError());
+        if (c->logN <= 14) {
+            ntt_io_t io = io_plain();
+            io.mode = 2; io.gsz = (u32)(2 * level); io.src_gstride = io.gsz; io.dst_gstride = io.gsz;
+            io.add_rows = add_s * (u32)level; io.add_gstride = (u32)(polys * level); io.addend = cin;
+            rc = run_ntt(c, true, S, cout, nb * 2 * level, A.w, &io);
+            if (rc) return rc;
+        } else {
+            rc = run_ntt(c, true, S, cout, nb * 2 * level, A.w);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_ks_add_ct, dim3((unsigned)(nb * 2 * level)), dim3(256), 0, c->stream, cin, cout, c->limbs_dev, Al, n, add_s);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return TFHE_OK;
 }
 
 // ---- profiling / events ---------------------------------------------------------------------------

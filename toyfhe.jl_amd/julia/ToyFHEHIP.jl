@@ -114,9 +114,16 @@ end
 # `pack(ek)` lays ek.key out as [digit][mask, masked][Lk][N] in the NTT domain (coeffs_dual), once per key.
 function ToyFHE.keyswitch(ek::KeySwitchKey, c::CipherText{Enc,P,<:RingElement{ℛ,T,<:HipVector}}) where {Enc,P,ℛ,T}
     @assert length(c.cs) in (2, 3)                                                    # rlwe_she.jl:318
-    ToyFHE.relin_window(ek.params) == 0 || return invoke(ToyFHE.keyswitch, Tuple{KeySwitchKey,CipherText}, ek, c)
     keyring = NTT.ring(ek.key[1].mask); Lk = length(moduli(keyring).parameters); level = length(moduli(ℛ).parameters)
     ct = pack(c); out = HipVector{T}(2level, degree(ℛ))
+    w = ToyFHE.relin_window(ek.params)
+    if w != 0                                                                         # K14, rlwe_she.jl:330-338
+        ek.params isa ModulusRaised && return invoke(ToyFHE.keyswitch, Tuple{KeySwitchKey,CipherText}, ek, c)
+        check(ccall((:tfhe_keyswitch_window, lib), Cint,
+                    (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}, Cint, Ptr{UInt64}, Cint, Ptr{UInt64}, Int64),
+                    hipring(ℛ).handle, level, w, pack(ek).ptr, length(ek.key), ct.ptr, length(c.cs), out.ptr, 1))
+        return CipherText{Enc}(c.params, unpack(out, ℛ, 2))
+    end
     check(ccall((:tfhe_keyswitch, lib), Cint,
                 (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{UInt64}, Cint, Ptr{UInt64}, Cint, Ptr{UInt64}, Int64),
                 hipring(keyring).handle, Lk, level, ek.params isa ModulusRaised, pack(ek).ptr, length(ek.key),

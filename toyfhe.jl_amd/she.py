@@ -422,21 +422,27 @@ def make_eval_key(rng, old: RingElement, new: PrivKey) -> KeySwitchKey:
     """make_eval_key(rng, old => new), rlwe_she.jl:273-298 with the RNS gadget (:287); ModulusRaised
     pre-multiplies ``old`` by the special prime (modulusraising.jl:28-32)."""
     params = new.params
-    if params.relin_window != 0:
-        raise NotImplementedError("digit-window (relin_window != 0) evaluation keys are host-only upstream "
-                                  "(rlwe_she.jl:281-283); the device path implements the RNS gadget")
     ring = old.ring
     if isinstance(params, ModulusRaised):
+        if params.relin_window != 0:
+            raise NotImplementedError("ModulusRaised with a digit window is not on the device path")
         old = old * ring.moduli[-1]
-    res = old.to_numpy("primal")
     key = []
-    for i in range(ring.L):
-        g = np.zeros_like(res)
-        g[i] = res[i]                                     # CRTResidual, crt.jl:64-77
+    if params.relin_window != 0:                          # base-2^w gadget, rlwe_she.jl:281-283
+        w = params.relin_window
+        nwin = -(-ring.modulus().bit_length() // w)       # ndigits(Q, base = 2^w)
+        gadget = [old * pow(2, i * w, ring.modulus()) for i in range(nwin)]
+    else:
+        res = old.to_numpy("primal")
+        gadget = []
+        for i in range(ring.L):
+            g = np.zeros_like(res)
+            g[i] = res[i]                                 # CRTResidual, crt.jl:64-77
+            gadget.append(RingElement.from_host(ring, g))
+    for g in gadget:
         mask = sample_uniform(rng, ring)
         e = params.noise(rng, ring)
-        masked = RingElement.from_host(ring, g) - (mask * new.secret + e)
-        key.append(KeyComponent(mask, masked))
+        key.append(KeyComponent(mask, g - (mask * new.secret + e)))
     return KeySwitchKey(params, key)
 
 
@@ -462,9 +468,18 @@ def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
     if len(c) not in (2, 3):
         raise AssertionError("keyswitch needs a 2- or 3-element ciphertext")  # rlwe_she.jl:318
     params = ek.params
-    if params.relin_window != 0:
-        raise NotImplementedError("digit-window keyswitch (relin_window != 0) is not on the device path")
     keyring = ek.key[0].mask.ring
+    if params.relin_window != 0:                          # base-2^w digits, rlwe_she.jl:330-338
+        if isinstance(params, ModulusRaised):
+            raise NotImplementedError("ModulusRaised with a digit window is not on the device path")
+        ring, n, batch = c[0].ring, c[0].count, c[0].batch
+        if ring.idx != list(range(ring.L)) or keyring.idx != ring.idx:
+            raise UsageError("window key switch: key ring and ciphertext ring must be the same prefix of the context")
+        cs = c.cs if _galois is None else [x.apply_galois_element(_galois) for x in c.cs]
+        ct = _pack([x.coeffs_primal() for x in cs], ring, n)
+        out = DeviceBuffer(n * 2 * ring.L * ring.N)
+        ring.ctx.keyswitch_window(ring.L, params.relin_window, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n)
+        return CipherText(c.params, _unpack(out, ring, n, 2, batch, primal=True), c.scale)
     special = isinstance(params, ModulusRaised)
     ring, n, batch = c[0].ring, c[0].count, c[0].batch
     level = ring.L
