@@ -8,6 +8,7 @@
 // Reference semantics: src/bfv.jl:34-40,172-226 via src/crt.jl:91-112 (see bfv_core.h for the derivation).
 #pragma once
 #include "conv_core.h"
+#include "fp64arith.h"
 
 template <int K>
 TFHE_HD u32 conv_alpha_fast(const u64 (&xi)[K], const u64* rho, const u32* sh, u64& frac_out) {
@@ -100,6 +101,11 @@ struct bfv_fast_tab_t {
     u64 n_cC2[TFHE_FAST_MAX][TFHE_FAST_MAX];    // [j][i]  (P/p_j) mod q_i
     u64 n_cNegA2[TFHE_FAST_MAX];                // -(P mod q_i)                 (times alpha_2)
     u64 n_cNegHalf[TFHE_FAST_MAX];              // -(floor(P/2) mod q_i)        (plain)
+    // exact-integer fp64 parts of the narrow path (every modulus below 1.125 * 2^50, fp64arith.h)
+    double f_q[TFHE_FAST_MAX], f_qinv[TFHE_FAST_MAX];   // q_i, 1/q_i
+    double f_p[TFHE_FAST_MAX], f_pinv[TFHE_FAST_MAX];   // p_j, 1/p_j
+    double f_ea[TFHE_FAST_MAX], f_eb[TFHE_FAST_MAX];    // expand:   xi_i = x_i ea_i + eb_i mod q_i  (ea = (q/q_i)^-1, eb = floor(q/2) ea)
+    double f_ca[TFHE_FAST_MAX], f_cb[TFHE_FAST_MAX];    // contract: xi_i = y_i ca_i + cb_i mod q_i  (c_a1, c_b1)
     // exact-alpha tables (word arrays in global memory)
     const u64 *Mq, *Aq, *Mp, *Ap;
     int nwq, nwp;
@@ -187,7 +193,7 @@ TFHE_HD void bfv_contract_fast(const bfv_fast_tab_t& B, const u64* src, size_t l
     }
 }
 
-// ---- narrow path: every modulus below 2^52 ----
+// ---- narrow path: every modulus below 1.125 * 2^50 ----
 TFHE_HD u64 pack26(u64 c) { return (c & 0x3ffffffull) | ((c >> 26) << 32); }
 TFHE_HD void acc52_macp(acc52& a, u64 x, u64 cpacked) {
     acc52_mac(a, (u32)x & 0x3ffffffu, (u32)(x >> 26), (u32)cpacked, (u32)(cpacked >> 32));
@@ -197,19 +203,38 @@ TFHE_HD u64 acc52_reduce(const acc52& a, const barrett_t& bt) {
     acc52_fold(a, lo, hi);
     return barrett_reduce128(lo, hi, bt);
 }
+// xi = (x a + b) mod p as an exact integer in a double, in [0, p)   (6-op fp64 modular product, fp64arith.h)
+TFHE_HD double fp_affine(u64 x, double a, double b, double p, double pinv) {
+    double r = fp_reduce(fp_mulmod_c(fp_from_u64(x), ftw_t{a}, p, pinv) + b, p, pinv);
+    return r < 0.0 ? r + p : r;
+}
+// alpha = floor(Σ xi_j / a_j) from a double sum: |S' - S| < K^2 2^-52 <= 2^-44 for K <= 16, so the floor is certain
+// unless the fraction is within 2^-40 of an integer -- then the exact multi-word comparison decides between the two
+// candidates.  (All three conversions are offset by floor(A/2), so that only happens for values near +-A/2.)
+template <int K>
+TFHE_HD u32 conv_alpha_fp(const double (&xd)[K], const u64 (&xi)[K], const double* ainv, const u64* M, const u64* Aw, int nwords) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < K; j++) s = fp_fma(xd[j], ainv[j], s);
+    const double fl = __builtin_floor(s), f = s - fl;
+    const u32 n = (u32)fl;
+    if (f > 0x1p-40 && f < 1.0 - 0x1p-40) return n;
+    if (f <= 0x1p-40) return n == 0 ? 0u : conv_alpha_exact<K>(xi, M, Aw, nwords, n - 1);
+    return conv_alpha_exact<K>(xi, M, Aw, nwords, n);
+}
 
 template <int NS, int NP>
 TFHE_HD void bfv_expand_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
     static_assert(NS + 2 <= 16 && NP + 2 <= 16, "acc52 term budget");
     u64 x[NS], xi[NS];
+    double xd[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) {
         x[i] = src[(size_t)i * ls];
-        xi[i] = shoup_full(addmod(x[i], B.e_half[i], B.q[i]), B.e_inv[i], B.q[i]);
+        xd[i] = fp_affine(x[i], B.f_ea[i], B.f_eb[i], B.f_q[i], B.f_qinv[i]);
+        xi[i] = fp_to_u64(xd[i]);
     }
-    u64 frac;
-    u32 alpha = conv_alpha_fast<NS>(xi, B.rho_q, B.sh_q, frac);
-    if (frac + 2ull * NS < frac) alpha = conv_alpha_exact<NS>(xi, B.Mq, B.Aq, B.nwq, alpha);
+    const u32 alpha = conv_alpha_fp<NS>(xd, xi, B.f_qinv, B.Mq, B.Aq, B.nwq);
 #pragma unroll
     for (int i = 0; i < NS; i++) dst[(size_t)B.pos_s[i] * ld] = x[i];
 #pragma unroll
@@ -225,13 +250,15 @@ TFHE_HD void bfv_expand_narrow(const bfv_fast_tab_t& B, const u64* src, size_t l
 template <int NS, int NP>
 TFHE_HD void bfv_contract_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
     u64 xi[NS];
+    double xd[NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++)  // ξ_i of r = (t y + h) mod q
-        xi[i] = addmod(shoup_full(src[(size_t)B.pos_s[i] * ls], B.c_a1[i], B.q[i]), B.c_b1[i], B.q[i]);
-    u64 frac;
-    u32 a1 = conv_alpha_fast<NS>(xi, B.rho_q, B.sh_q, frac);
-    if (frac + 2ull * NS < frac) a1 = conv_alpha_exact<NS>(xi, B.Mq, B.Aq, B.nwq, a1);
+    for (int i = 0; i < NS; i++) {  // ξ_i of r = (t y + h) mod q
+        xd[i] = fp_affine(src[(size_t)B.pos_s[i] * ls], B.f_ca[i], B.f_cb[i], B.f_q[i], B.f_qinv[i]);
+        xi[i] = fp_to_u64(xd[i]);
+    }
+    const u32 a1 = conv_alpha_fp<NS>(xd, xi, B.f_qinv, B.Mq, B.Aq, B.nwq);
     u64 xp[NP];
+    double xpd[NP];
 #pragma unroll
     for (int j = 0; j < NP; j++) {  // ξ'_j of w + floor(P/2) in basis P: one product-sum, one reduction
         acc52 a{B.c_b2[j], 0, 0};
@@ -240,9 +267,9 @@ TFHE_HD void bfv_contract_narrow(const bfv_fast_tab_t& B, const u64* src, size_t
         for (int i = 0; i < NS; i++) acc52_macp(a, xi[i], B.n_cNegC1[i][j]);
         acc52_macp(a, (u64)a1, B.n_cA1[j]);
         xp[j] = acc52_reduce(a, B.pb[j]);
+        xpd[j] = fp_from_u64(xp[j]);
     }
-    u32 a2 = conv_alpha_fast<NP>(xp, B.rho_p, B.sh_p, frac);
-    if (frac + 2ull * NP < frac) a2 = conv_alpha_exact<NP>(xp, B.Mp, B.Ap, B.nwp, a2);
+    const u32 a2 = conv_alpha_fp<NP>(xpd, xp, B.f_pinv, B.Mp, B.Ap, B.nwp);
 #pragma unroll
     for (int i = 0; i < NS; i++) {
         acc52 a{B.n_cNegHalf[i], 0, 0};

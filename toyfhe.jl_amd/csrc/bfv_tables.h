@@ -185,8 +185,17 @@ inline bool build_bfv_fast_host(const std::vector<u64>& qs, const std::vector<u6
         }
     }
     auto lazy_of = [](int bits, int k) { const int room = 62 - bits; return std::max(1, std::min(k, room >= 20 ? (1 << 20) : (1 << std::max(0, room)))); };
-    B.narrow = (maxq <= 52 && maxp <= 52 && ns + 2 <= 16 && np + 2 <= 16) ? 1 : 0;
+    u64 maxmod = 0;
+    for (u64 x : qs) maxmod = std::max(maxmod, x);
+    for (u64 x : P) maxmod = std::max(maxmod, x);
+    B.narrow = (maxmod < TFHE_FP_QMAX && ns + 2 <= 16 && np + 2 <= 16) ? 1 : 0;
     if (B.narrow) {
+        for (int i = 0; i < ns; i++) {
+            B.f_q[i] = (double)qs[i]; B.f_qinv[i] = 1.0 / (double)qs[i];
+            B.f_ea[i] = (double)B.e_inv[i].w; B.f_eb[i] = (double)mulmod_slow(B.e_half[i], B.e_inv[i].w, qs[i]);
+            B.f_ca[i] = (double)B.c_a1[i].w; B.f_cb[i] = (double)B.c_b1[i];
+        }
+        for (int j = 0; j < np; j++) { B.f_p[j] = (double)P[j]; B.f_pinv[j] = 1.0 / (double)P[j]; }
         auto neg = [](u64 c, u64 m) { return c ? m - c : 0; };
         for (int j = 0; j < np; j++) {
             const u64 pj = P[j];
