@@ -12,6 +12,7 @@
 
 #define TFHE_EMUL_COUNT_SLOW 1
 static long g_slow_hits = 0;
+static double g_fp_max_ratio = 0;  // fp64arith.h TFHE_TRACK
 #include "../../toyfhe.jl_amd/csrc/bfv_tables.h"
 #include "../../toyfhe.jl_amd/csrc/ntt_tables.h"
 
@@ -195,3 +196,10 @@ int emul_bfv_fast(const uint64_t* qs, int ns, const uint64_t* pb, int nb, uint64
 }
 
 }  // extern "C"
+
+// largest |value| / p seen by the fp64 modular products / reductions since the last call (range-budget check)
+extern "C" double emul_fp_max_ratio_reset() {
+    const double r = g_fp_max_ratio;
+    g_fp_max_ratio = 0;
+    return r;
+}

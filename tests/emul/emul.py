@@ -23,6 +23,7 @@ def lib():
         L.emul_bfv.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_uint64, C.c_int, C.c_int64, u64p, u64p, C.c_long,
                                C.POINTER(C.c_long)]
         L.emul_bfv_fast.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_uint64, C.c_int, C.c_int64, u64p, u64p, C.c_long]
+        L.emul_fp_max_ratio_reset.restype = C.c_double
         _LIB = L
     return _LIB
 
@@ -81,3 +82,8 @@ def bfv_fast(qs, pb, t, src, N, contract):
     if rc:
         raise RuntimeError(f"emul_bfv_fast rc={rc}")
     return out
+
+
+def fp_max_ratio_reset():
+    """largest |operand| / p that entered an fp64 modular product or reduction since the last call"""
+    return lib().emul_fp_max_ratio_reset()

@@ -46,6 +46,7 @@ def test_fp64_butterflies_at_the_modulus_limit_and_worst_case_inputs(logn):
     ctx = ref_cpu.RefCtx(N, [q])
     pats = [np.full(N, q - 1, dtype=np.uint64), np.array([0, q - 1] * (N // 2), dtype=np.uint64),
             np.full(N, (q - 1) // 2, dtype=np.uint64), np.random.default_rng(logn).integers(0, q, size=N, dtype=np.uint64)]
+    emul.fp_max_ratio_reset()
     for a in pats:
         want = ctx.nntt(a.reshape(1, 1, N)).reshape(N)
         assert np.array_equal(emul.ntt(a, q, variant=0), want)
@@ -54,6 +55,9 @@ def test_fp64_butterflies_at_the_modulus_limit_and_worst_case_inputs(logn):
         # inverse on growth-maximising NTT-domain inputs as well
         wi = ctx.inntt(a.reshape(1, 1, N)).reshape(N)
         assert np.array_equal(emul.ntt(a, q, inverse=True, variant=0), wi)
+    # every operand of a modular product / reduction stayed inside the exactness budget: |v| < 2^53 (7.1 p at this modulus)
+    worst = emul.fp_max_ratio_reset()
+    assert 0 < worst < 2.0**53 / q, worst
 
 
 @pytest.mark.parametrize("logn", [15, 16])

@@ -14,7 +14,9 @@
 // Range bookkeeping (in units of p, a = p 2^-52 <= 0.28125, growth per forward stage b' = b (1 + 1.5 a) + 1/2):
 //   forward, from |v| <= 1/2 (LDS values are reduced, global inputs are centred):
 //        1.21, 2.22, 3.66, 5.70 after 1..4 stages  < 2^53 / p >= 7.1;  5-stage passes reduce after stage 3
-//   inverse, reduce after every third stage: sums double (1/2 -> 4), products stay <= 1/2 + 1.5 a 4 = 2.2
+//        (a 5-stage first pass may also start from uncentred residues: 1 -> 1.92 -> 3.23 -> 5.10, sweep, ...)
+//   inverse: sums double per stage, products return to <= 1/2 + 1.5 a b; only the operands whose sum would pass 7 p are
+//        reduced, by a compile-time plan (ntt_core.h make_inv_plan)
 #pragma once
 #include "modarith.h"
 
@@ -28,13 +30,23 @@ typedef double ftwd_t;  // table entry
 TFHE_HD double fp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 TFHE_HD double fp_rint(double x) { return __builtin_rint(x); }
 
+#if defined(TFHE_EMUL_TRACK_RANGE) && !defined(__HIP_DEVICE_COMPILE__)
+// CPU emulation only (tests/emul): largest |operand| / p that ever entered a modular product or a reduction
+#define TFHE_TRACK(v, p) do { const double r_ = ((v) < 0 ? -(v) : (v)) / (p); if (r_ > g_fp_max_ratio) g_fp_max_ratio = r_; } while (0)
+#else
+#define TFHE_TRACK(v, p) ((void)0)
+#endif
 TFHE_HD double fp_mulmod_c(double y, ftw_t t, double p, double pinv) {
+    TFHE_TRACK(y, p);
     const double h = t.w * y;
     const double l = fp_fma(t.w, y, -h);
     const double k = fp_rint(h * pinv);
     return fp_fma(-k, p, h) + l;
 }
-TFHE_HD double fp_reduce(double v, double p, double pinv) { return fp_fma(-fp_rint(v * pinv), p, v); }
+TFHE_HD double fp_reduce(double v, double p, double pinv) {
+    TFHE_TRACK(v, p);
+    return fp_fma(-fp_rint(v * pinv), p, v);
+}
 
 // exact conversions for 0 <= x < 2^52
 TFHE_HD double fp_from_u64(u64 x) {

@@ -151,6 +151,7 @@ struct ArithInt {
     static TFHE_HD tw ld_inv_b(const ctx& c, u32 i) { return ld_tw(c.Winvb, i); }
     static TFHE_HD bool has_b(const ctx& c) { return c.Wb != nullptr; }
     static TFHE_HD elem from_global(u64 x, const ctx&) { return x; }
+    static TFHE_HD elem from_global_plain(u64 x, const ctx&) { return x; }
     static TFHE_HD elem from_global_lift(u64 x, const ctx&, const lift_t& f) { return lift_digit(x, f); }
     static TFHE_HD elem from_lds(u64 x) { return x; }
     static TFHE_HD u64 to_lds(elem v) { return v; }
@@ -195,6 +196,7 @@ struct ArithFp {
         const double d = fp_from_u64(x);
         return d + d > c.p ? d - c.p : d;
     }
+    static TFHE_HD elem from_global_plain(u64 x, const ctx&) { return fp_from_u64(x); }
     // digit lift in fp64: centred residue of limb i (|d| <= q_i/2 < 2^51, exact) reduced mod p_j
     static TFHE_HD elem from_global_lift(u64 x, const ctx& c, const lift_t& f) {
         double d = fp_from_u64(x);
@@ -363,7 +365,10 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
 #pragma unroll
         for (int r = 0; r < G::R; r++) {
             if (FIRST && (lift || SPLIT)) continue;
-            vv[r] = FIRST ? A::from_global(raw[u * G::R + r], C) : A::from_lds(raw[u * G::R + r]);
+            // 5-stage first passes sweep the range after their third stage, so residues may enter uncentred (|v| < p:
+            // 1 -> 1.92 -> 3.23 -> 5.10 p, fp64arith.h); 4-stage passes have no sweep and need |v| <= p/2
+            vv[r] = FIRST ? (K >= 5 ? A::from_global_plain(raw[u * G::R + r], C) : A::from_global(raw[u * G::R + r], C))
+                          : A::from_lds(raw[u * G::R + r]);
         }
 #pragma unroll
         for (int d = 0; d < K; d++) {
@@ -458,6 +463,38 @@ TFHE_HD void inv_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, i
     TFHE_SCHED_FENCE();
 #endif
 }
+// Range plan of an inverse pass (fp64 policy): sums double per Gentleman-Sande stage while products come back to
+// <= 1/2 + 1.5 a b, so only the elements on long runs of sums ever approach the exactness limit.  Instead of sweeping
+// all 2^K registers every third stage, reduce exactly the operands whose sum would exceed the limit (bounds in units of
+// p for the worst admissible modulus, a = 1.125 * 2^50 / 2^52; limit 7 < 2^53 / (1.125 * 2^50)): 10 reductions in a
+// 5-stage pass instead of 32, 2 instead of 16 in a 4-stage pass.  mask[s] = registers reduced before processed stage s.
+struct inv_plan_t {
+    u32 mask[8];
+};
+template <int K>
+constexpr inv_plan_t make_inv_plan() {
+    inv_plan_t P{};
+    constexpr double a = 0.28125, lim = 7.0, b0 = 0.502;
+    double b[1 << K] = {};
+    for (int i = 0; i < (1 << K); i++) b[i] = b0;
+    for (int st = 0; st < K; st++) {
+        const int d = K - 1 - st, half = 1 << st;
+        for (int g = 0; g < (1 << d); g++)
+            for (int i = 0; i < half; i++) {
+                const int r0 = (g << (K - d)) + i, r1 = r0 + half;
+                while (b[r0] + b[r1] > lim) {
+                    const int m = b[r0] >= b[r1] ? r0 : r1;
+                    b[m] = b0;
+                    P.mask[st] |= 1u << m;
+                }
+                const double sm = b[r0] + b[r1];
+                b[r0] = sm;
+                b[r1] = 0.5 + 1.5 * a * sm + 0.002;
+            }
+    }
+    return P;
+}
+
 // Inverse butterflies (stage K-1 first).  Stages d >= K-PF come from `twp`; the others are loaded here.
 template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE, int PF, int USEL = -1, class HOOK = no_hook>
 TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
@@ -476,6 +513,12 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
 #pragma unroll
         for (int d = K - 1; d >= 0; d--) {
             const int half = 1 << (K - 1 - d);
+            {
+                constexpr inv_plan_t PLAN = make_inv_plan<K>();
+#pragma unroll
+                for (int r = 0; r < G::R; r++)
+                    if ((PLAN.mask[K - 1 - d] >> r) & 1u) A::range_inv(vv[r], C);
+            }
 #pragma unroll
             for (int g = 0; g < (1 << d); g++) {
                 if (SCALE && S0 == 0 && d == 0) {
@@ -493,12 +536,6 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
                 }
                 hook(((u * K + (K - 1 - d)) * (G::R / 2)) + g * half, ((u * K + (K - 1 - d)) * (G::R / 2)) + (g + 1) * half,
                      G::SETS * K * (G::R / 2));
-            }
-            // range control after every third processed stage (pass ends are handled by the store): sums double per
-            // stage, 1/2 -> 4 over three stages, products stay <= 2.2 (fp64arith.h)
-            if (((K - 1 - d) % 3) == 2 && d != 0) {
-#pragma unroll
-                for (int r = 0; r < G::R; r++) A::range_inv(vv[r], C);
             }
         }
     }
