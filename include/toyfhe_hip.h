@@ -125,6 +125,17 @@ int tfhe_rotate(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint
  *   window_bits: 1..32 with 2^w below every modulus.   ct / out as tfhe_keyswitch. */
 int tfhe_keyswitch_window(tfhe_ctx *ctx, int level, int window_bits, const uint64_t *evk, int n_windows, const uint64_t *ct, int polys, uint64_t *out, int64_t batch);
 
+/* ---- CKKS encode / decode (float; ckksencoding.jl:56-97, FixedRational ckks.jl:35-59) -- SURVEY §8(f) ----
+ * The ring is limbs 0..level-1 of ctx.  scale = scale_mant * 2^scale_exp2 (2^40 = (1, 40); any positive scale to
+ * 2^-63 relative).  slots: [batch][N/2] complex doubles (re, im interleaved), device memory.
+ *   encode: slots -> ifft over the (Z/2N)^* orbit + psi-twist -> n_k = round(x_k * scale) (exact product, ties to even,
+ *           ckks.jl:42) -> residues [batch][level][N], coefficient domain.
+ *   decode: residues -> centred integer (exact CRT) -> Float64(n / scale) -> conj twist -> fft -> slots.
+ * Float path: transform summation order differs from FFTW, so results agree with the reference to rounding
+ * (encode: integers equal up to +-1 at rounding boundaries; decode: |err| <= 8 log2(N) eps max|slot|). */
+int tfhe_ckks_encode(tfhe_ctx *ctx, int level, uint64_t scale_mant, int scale_exp2, const double *slots, uint64_t *out, int64_t batch);
+int tfhe_ckks_decode(tfhe_ctx *ctx, int level, uint64_t scale_mant, int scale_exp2, const uint64_t *in, double *slots, int64_t batch);
+
 /* ---- K12/K13: BFV multiplication (rlwe_she.jl:247-262 with bfv.jl:34-40,172-226) ---------------
  * plan = (ℛ = small ctx limbs idx_s, ℛbig = big ctx limbs idx_b, t).  Supported basis relations:
  * ℛbig ⊇ ℛ as sets of primes, or disjoint (test/bfv_crt.jl); anything else TFHE_E_UNSUPPORTED.

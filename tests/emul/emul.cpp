@@ -15,6 +15,7 @@ static long g_slow_hits = 0;
 static double g_fp_max_ratio = 0;  // fp64arith.h TFHE_TRACK
 #include "../../toyfhe.jl_amd/csrc/bfv_tables.h"
 #include "../../toyfhe.jl_amd/csrc/ntt_tables.h"
+#include "../../toyfhe.jl_amd/csrc/ckks_core.h"
 
 namespace {
 
@@ -202,4 +203,14 @@ extern "C" double emul_fp_max_ratio_reset() {
     const double r = g_fp_max_ratio;
     g_fp_max_ratio = 0;
     return r;
+}
+
+// ckks_core.h: n = round(x * smant * 2^sexp) mod q for `count` doubles (encode tail), and the inverse conversion of a
+// signed multi-word magnitude to a double (decode head)
+extern "C" void emul_ckks_round(const double* x, long count, uint64_t smant, int sexp, uint64_t q, uint64_t* out) {
+    const barrett_t bt = hostmath::make_barrett(q);
+    for (long i = 0; i < count; i++) out[i] = ckks_residue(ckks_round_scaled(x[i], smant, sexp), bt);
+}
+extern "C" double emul_ckks_to_double(const uint64_t* w, int nwords, int neg, uint64_t smant, int sexp) {
+    return ckks_words_to_double(w, nwords, neg != 0, smant, sexp);
 }

@@ -24,6 +24,10 @@ def lib():
                                C.POINTER(C.c_long)]
         L.emul_bfv_fast.argtypes = [u64p, C.c_int, u64p, C.c_int, C.c_uint64, C.c_int, C.c_int64, u64p, u64p, C.c_long]
         L.emul_fp_max_ratio_reset.restype = C.c_double
+        L.emul_ckks_round.argtypes = [C.POINTER(C.c_double), C.c_long, C.c_uint64, C.c_int, C.c_uint64, u64p]
+        L.emul_ckks_round.restype = None
+        L.emul_ckks_to_double.argtypes = [u64p, C.c_int, C.c_int, C.c_uint64, C.c_int]
+        L.emul_ckks_to_double.restype = C.c_double
         _LIB = L
     return _LIB
 
@@ -87,3 +91,16 @@ def bfv_fast(qs, pb, t, src, N, contract):
 def fp_max_ratio_reset():
     """largest |operand| / p that entered an fp64 modular product or reduction since the last call"""
     return lib().emul_fp_max_ratio_reset()
+
+
+def ckks_round(x, smant, sexp, q):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty(x.size, dtype=np.uint64)
+    lib().emul_ckks_round(x.ctypes.data_as(C.POINTER(C.c_double)), x.size, int(smant), int(sexp), int(q), _p(out))
+    return out
+
+
+def ckks_to_double(mag: int, neg: bool, smant, sexp):
+    nwords = max(1, -(-mag.bit_length() // 64))
+    w = np.array([(mag >> (64 * i)) & (2**64 - 1) for i in range(nwords)], dtype=np.uint64)
+    return lib().emul_ckks_to_double(_p(w), nwords, int(neg), int(smant), int(sexp))

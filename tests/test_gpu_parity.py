@@ -483,3 +483,57 @@ def test_full_size_ntt_properties():
         for c in reversed([int(v) for v in a[0, 0]]):
             acc = (acc * x + c) % q
         assert acc == int(fa[0, 0, k])
+
+
+# ---------------------------------------------------------------------------------------------------
+# CKKS encode / decode on the device (float -- tolerances as stated in SURVEY §8 a18)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,bits,L,scale", [(32, 40, 3, 2**40), (4096, 50, 2, 2**40), (64, 60, 1, 2**30), (32, 40, 3, 2**80),
+                                             (16, 50, 2, 12345 * 2**20), (1 << 15, 50, 1, 2**30)])
+def test_ckks_encode_decode_match_oracle(N, bits, L, scale):
+    """tfhe_ckks_encode / tfhe_ckks_decode against the numpy restatement of ckksencoding.jl:56-97 (oracle/spec.py).
+    encode: integer coefficients equal to the oracle's except +-1 at rounding boundaries (different FFT summation
+    order; for scales beyond 2^53 a last-place difference of the double is worth scale * ulp); decode: per-slot error
+    <= 8 log2(N) eps max|slot|."""
+    qs = H.chain(bits, L, N)
+    ring = spec.Ring(N, qs)
+    ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(N + L)
+    batch = 1 if N > 4096 else 3
+    slots = rng.normal(size=(batch, N // 2)) * 3 + 1j * rng.normal(size=(batch, N // 2))
+    slots[0, :4] = [1.0, -2.5, 0.0, 1j]
+    mant, exp2 = tf.she.scale_parts(scale)
+    dz = tf.DeviceBuffer.from_numpy(np.ascontiguousarray(slots).view(np.uint64))
+    dout = tf.DeviceBuffer(batch * L * N)
+    ctx.ckks_encode(L, mant, exp2, dz.ptr, dout.ptr, batch)
+    res = dout.to_numpy((batch, L, N))
+    eps = 2.0 ** -53
+    for b in range(batch):
+        want = spec.poly_to_ints(spec.ckks_encode(list(slots[b]), ring, scale), ring)
+        got = spec.poly_to_ints([list(map(int, l)) for l in res[b]], ring)
+        diff = [spec.centred(g - w, ring.Q) for g, w in zip(got, want)]
+        # one unit at a rounding boundary; beyond 53 bits of scale a last-place difference of x scales up with it
+        allowed = max(1, int(8 * np.log2(N) * eps * np.abs(slots[b]).max() * float(scale)))
+        assert max(abs(d) for d in diff) <= allowed, (max(abs(d) for d in diff), allowed)
+        if allowed == 1:
+            assert sum(1 for d in diff if d) <= max(2, N // 20)      # boundary flips are rare
+        # decode of the device encoding against the oracle's decode of the same residues
+        dslots = tf.DeviceBuffer(N)
+        one = tf.DeviceBuffer.from_numpy(res[b])
+        ctx.ckks_decode(L, mant, exp2, one.ptr, dslots.ptr, 1)
+        dec = dslots.to_numpy().view(np.complex128)
+        ref = spec.ckks_decode([list(map(int, l)) for l in res[b]], ring, scale)
+        tol = 8 * np.log2(N) * eps * max(1.0, np.abs(ref).max()) * 4
+        assert np.abs(dec - ref).max() <= tol, (np.abs(dec - ref).max(), tol)
+        assert np.abs(dec - slots[b]).max() <= N * 2.0 / float(scale) + tol   # round trip: quantisation 1/scale per coefficient
+    # decode of arbitrary ring elements (uniform residues: magnitudes up to Q / 2 scale)
+    a = H.rand_residues(rng, qs, (1,), N)
+    da, dslots = dev(a), tf.DeviceBuffer(N)
+    ctx.ckks_decode(L, mant, exp2, da.ptr, dslots.ptr, 1)
+    dec = dslots.to_numpy().view(np.complex128)
+    ref = spec.ckks_decode([list(map(int, l)) for l in a[0]], ring, scale)
+    assert np.abs(dec - ref).max() <= 32 * np.log2(N) * eps * np.abs(ref).max()
+    with pytest.raises(AssertionError):
+        ctx.ckks_encode(L, 0, 0, dz.ptr, dout.ptr, 1)                 # scale must be positive
+    with pytest.raises(tf.UsageError):
+        ctx.ckks_encode(L + 1, 1, 40, dz.ptr, dout.ptr, 1)

@@ -219,3 +219,35 @@ def test_window_digit_bodies(bits, k, w):
     got = emul.window_digits(qs, w, nwin, res)
     want = np.array([[(x >> (i * w)) & ((1 << w) - 1) for i in range(nwin)] for x in xs], dtype=np.uint64)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("smant,sexp", [(1, 40), (1, 80), (1, 0), (12345, 30), (2**63 + 12345, -20), (1, 200)])
+def test_ckks_fixed_point_conversions(smant, sexp):
+    """ckks_core.h against exact rational arithmetic: round(BigInt, big(x) * scale) with ties to even, reduced mod q
+    (ckks.jl:42-45), and Float64(n / scale) for multi-word n (ckks.jl:52-58)."""
+    from fractions import Fraction
+    scale = Fraction(smant) * Fraction(2) ** sexp
+    q = _chain(50, 1, 64)[0]
+    rng = random.Random(smant % 1000 + sexp)
+    xs = [0.0, -0.0, 1.0, -1.0, 0.5, 1.5, 2.5, -2.5, 1e-30, -1e-30, 5e-324, 123456.789, -3.75e10, 2.0**-41, 3 * 2.0**-41, -(2.0**-41),
+          float(Fraction(1, 2) / scale) if scale < 2**1000 else 0.0, float(Fraction(3, 2) / scale) if scale < 2**1000 else 0.0]
+    xs += [rng.uniform(-4, 4) * 2.0 ** rng.randint(-60, 20) for _ in range(400)]
+    got = emul.ckks_round(np.array(xs), smant, sexp, q)
+
+    def rne(fr):
+        fl = fr.numerator // fr.denominator
+        rem = fr - fl
+        return fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2 == 1) else 0)
+    want = [rne(Fraction(x) * scale) % q for x in xs]
+    assert [int(g) for g in got] == want
+    # magnitude -> double: nearest double of n / scale (one rounding for power-of-two scales)
+    for _ in range(300):
+        bits = rng.randint(1, 400)
+        mag = rng.getrandbits(bits) | (1 << (bits - 1))
+        neg = rng.random() < 0.5
+        got_d = emul.ckks_to_double(mag, neg, smant, sexp)
+        exact = Fraction(-mag if neg else mag) / scale
+        if smant == 1:
+            assert got_d == float(exact), (mag, neg)
+        else:
+            assert abs(Fraction(got_d) - exact) <= abs(exact) * Fraction(1, 2**51)

@@ -17,6 +17,7 @@
 #include "bfv_tables.h"
 #include "host_math.h"
 #include "kernels.h"
+#include "ckks_kernels.h"
 #include "ntt_tables.h"
 
 namespace {
@@ -62,6 +63,8 @@ struct tfhe_ctx {
     // profiling
     bool prof = false;
     std::vector<prof_pair> prof_pairs;
+    // CKKS encode / decode tables (built on first use): FFT roots, twist, scatter / gather positions
+    void *ckks_roots = nullptr, *ckks_tw = nullptr, *ckks_pos = nullptr, *ckks_gpos = nullptr;
     // exact-reconstruction tables of the window key switch, per level (built on first use)
     std::map<int, conv_tab_t*> ksw_tabs;
     std::vector<void*> ksw_allocs;
@@ -738,6 +741,118 @@ int tfhe_keyswitch_window(tfhe_ctx* c, int level, int window_bits, const uint64_
             hipLaunchKernelGGL(k_ks_add_ct, dim3((unsigned)(nb * 2 * level)), dim3(256), 0, c->stream, cin, cout, c->limbs_dev, Al, n, add_s);
             HIP_TRY(hipGetLastError());
         }
+    }
+    return TFHE_OK;
+}
+
+// ---- CKKS encode / decode (float; ckksencoding.jl:56-97, ckks.jl:35-59) -------------------------------------------
+static int ckks_tables(tfhe_ctx* c) {
+    std::lock_guard<std::mutex> g(c->ksw_mu);
+    if (c->ckks_roots) return TFHE_OK;
+    const size_t n = (size_t)c->N, n2 = n / 2;
+    const int logn = c->logN;
+    std::vector<double> roots(n2 * 2 + 2), tw(n * 2);
+    for (size_t t = 0; t < n2; t++) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)t / (long double)n;
+        roots[2 * t] = (double)cosl(a);
+        roots[2 * t + 1] = (double)sinl(a);
+    }
+    for (size_t k = 0; k < n; k++) {
+        // ckksencoding.jl:84: the angle 2k/(2N)*pi is evaluated in Float64 first, then exponentiated
+        const double ang = ((double)(2 * k) / (double)(2 * n)) * 3.14159265358979323846;
+        tw[2 * k] = cos(ang);
+        tw[2 * k + 1] = sin(ang);
+    }
+    auto brev = [&](u32 x) { u32 r = 0; for (int i = 0; i < logn; i++) r |= ((x >> i) & 1u) << (logn - 1 - i); return r; };
+    std::vector<u32> pos(2 * n2), gpos(n2);
+    const u64 M = 2 * n;
+    u64 e = 1;
+    for (size_t i = 0; i < n2; i++) {
+        e = (e * 3) % M;                       // 3^(i+1) mod 2N   (ZmstarPermutation, ckksencoding.jl:49-54)
+        pos[2 * i] = brev((u32)(e >> 1));
+        pos[2 * i + 1] = brev((u32)(((M - e) % M) >> 1));
+        gpos[i] = brev((u32)(e >> 1));
+    }
+    auto up = [&](const void* h, size_t bytes, void** d) -> bool {
+        if (hipMalloc(d, bytes ? bytes : 8) != hipSuccess) return false;
+        c->ksw_allocs.push_back(*d);
+        return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    void *r = nullptr, *t = nullptr, *p = nullptr, *gp = nullptr;
+    if (!up(roots.data(), (n2 ? n2 : 1) * 16, &r) || !up(tw.data(), n * 16, &t) || !up(pos.data(), pos.size() * 4, &p) ||
+        !up(gpos.data(), gpos.size() * 4, &gp))
+        return fail(TFHE_E_NOMEM, "allocating the CKKS tables failed");
+    c->ckks_tw = t; c->ckks_pos = p; c->ckks_gpos = gp; c->ckks_roots = r;
+    return TFHE_OK;
+}
+static int ckks_check(tfhe_ctx* c, int level, uint64_t smant, const void* a, const void* b, int64_t batch) {
+    if (!c || !a || !b) return fail(TFHE_E_BADARG, "null argument");
+    if (level < 1 || level > c->L) return fail(TFHE_E_LEVEL_MISMATCH, "level=%d outside [1,%d]", level, c->L);
+    if (smant == 0) return fail(TFHE_E_BADARG, "scale must be positive");
+    if (c->N < 4) return fail(TFHE_E_UNSUPPORTED, "CKKS encoding needs N >= 4");
+    if (batch < 0) return fail(TFHE_E_BADARG, "negative batch");
+    return TFHE_OK;
+}
+static int ckks_fft(tfhe_ctx* c, cplx_t* buf, int64_t nb, bool dif, bool conj_roots) {
+    const u32 n = (u32)c->N;
+    const dim3 grid((n / 2 + 255) / 256, (unsigned)nb);
+    if (dif) for (u32 h = n / 2; h >= 1; h >>= 1) hipLaunchKernelGGL(k_fft_pass, grid, dim3(256), 0, c->stream, buf, (const cplx_t*)c->ckks_roots, n, h, 1, conj_roots ? 1 : 0);
+    else for (u32 h = 1; h < n; h <<= 1) hipLaunchKernelGGL(k_fft_pass, grid, dim3(256), 0, c->stream, buf, (const cplx_t*)c->ckks_roots, n, h, 0, conj_roots ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
+int tfhe_ckks_encode(tfhe_ctx* c, int level, uint64_t scale_mant, int scale_exp2, const double* slots, uint64_t* out, int64_t batch) {
+    int rc = ckks_check(c, level, scale_mant, slots, out, batch);
+    if (rc || batch == 0) return rc;
+    rc = ckks_tables(c);
+    if (rc) return rc;
+    const u32 n = (u32)c->N;
+    limb_sel_t sel;
+    sel.n = level;
+    for (int j = 0; j < level; j++) sel.idx[j] = j;
+    const int64_t chunk = std::min<int64_t>(batch, 4096);
+    void* ws = nullptr;
+    rc = ensure_ws(c, (size_t)chunk * n * 16, &ws);
+    if (rc) return rc;
+    cplx_t* buf = (cplx_t*)ws;
+    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int64_t nb = std::min(chunk, batch - b0);
+        hipLaunchKernelGGL(k_ckks_scatter, dim3((n / 2 + 255) / 256, (unsigned)nb), dim3(256), 0, c->stream,
+                           (const cplx_t*)slots + (size_t)b0 * (n / 2), buf, (const u32*)c->ckks_pos, n);
+        rc = ckks_fft(c, buf, nb, false, true);  // inverse transform: conjugate roots, 1/N applied below
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_ckks_encode_finish, dim3((n + 255) / 256, (unsigned)nb), dim3(256), 0, c->stream, buf, (const cplx_t*)c->ckks_tw,
+                           out + (size_t)b0 * level * n, c->limbs_dev, sel, scale_mant, scale_exp2, n);
+        HIP_TRY(hipGetLastError());
+    }
+    return TFHE_OK;
+}
+
+int tfhe_ckks_decode(tfhe_ctx* c, int level, uint64_t scale_mant, int scale_exp2, const uint64_t* in, double* slots, int64_t batch) {
+    int rc = ckks_check(c, level, scale_mant, in, slots, batch);
+    if (rc || batch == 0) return rc;
+    rc = ckks_tables(c);
+    if (rc) return rc;
+    const conv_tab_t* T = nullptr;
+    rc = ksw_table(c, level, &T);
+    if (rc) return rc;
+    const u32 n = (u32)c->N;
+    const int64_t chunk = std::min<int64_t>(batch, 4096);
+    void* ws = nullptr;
+    rc = ensure_ws(c, (size_t)chunk * n * 16, &ws);
+    if (rc) return rc;
+    cplx_t* buf = (cplx_t*)ws;
+    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int64_t nb = std::min(chunk, batch - b0);
+        hipLaunchKernelGGL(k_ckks_decode_start, dim3((n + 255) / 256, (unsigned)nb), dim3(256), 0, c->stream, in + (size_t)b0 * level * n, buf,
+                           (const cplx_t*)c->ckks_tw, T, level, c->q[0], scale_mant, scale_exp2, n);
+        HIP_TRY(hipGetLastError());
+        rc = ckks_fft(c, buf, nb, true, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_ckks_gather, dim3((n / 2 + 255) / 256, (unsigned)nb), dim3(256), 0, c->stream, buf,
+                           (cplx_t*)slots + (size_t)b0 * (n / 2), (const u32*)c->ckks_gpos, n);
+        HIP_TRY(hipGetLastError());
     }
     return TFHE_OK;
 }

@@ -131,6 +131,22 @@ function ToyFHE.keyswitch(ek::KeySwitchKey, c::CipherText{Enc,P,<:RingElement{â„
     CipherText{Enc}(c.params, unpack(out, â„›, 2))
 end
 
+# ---- CKKS encode / decode (ckksencoding.jl:56-97) on the device ---------------------------------------
+# ScaleT = FixedRational{denom}: denom = mant * 2^exp2 (scale_parts as in toyfhe.jl_amd/she.py).
+function Base.convert(::Type{<:RingElement{â„›,T,S}}, s::CKKSEncoding{FixedRational{denom}}) where {â„›,T,S<:HipVector{T},denom}
+    mant, exp2 = scale_parts(denom); slots = upload(reinterpret(Float64, collect(s.data)))
+    out = HipVector{T}(length(moduli(â„›).parameters), degree(â„›))
+    check(ccall((:tfhe_ckks_encode, lib), Cint, (Ptr{Cvoid}, Cint, UInt64, Cint, Ptr{Float64}, Ptr{UInt64}, Int64),
+                hipring(â„›).handle, out.limbs, mant, exp2, slots.ptr, out.ptr, 1))
+    RingElement{â„›}(OffsetArray(out, 0:degree(â„›)-1), nothing)
+end
+function ToyFHE.CKKSEncoding{FixedRational{denom}}(plain::RingElement{â„›,T,S}) where {â„›,T,S<:HipVector{T},denom}
+    mant, exp2 = scale_parts(denom); src = NTT.coeffs_primal(plain).parent; slots = HipVector{Float64}(1, degree(â„›))
+    check(ccall((:tfhe_ckks_decode, lib), Cint, (Ptr{Cvoid}, Cint, UInt64, Cint, Ptr{UInt64}, Ptr{Float64}, Int64),
+                hipring(â„›).handle, src.limbs, mant, exp2, src.ptr, slots.ptr, 1))
+    CKKSEncoding{FixedRational{denom}}(typeof(plain), OffsetArray(reinterpret(ComplexF64, download(slots)), 0:degree(â„›)Ã·2-1))
+end
+
 # ---- K12/K13: BFV enc_mul (rlwe_she.jl:247-262 + bfv.jl:34-40) --------------------------------------
 # plan(params) = tfhe_bfv_plan_create(hipring(â„›), idx, hipring(â„›big), idx, t), cached per BFVParams.
 function ToyFHE.enc_mul(c1::CipherText{E,BFVParams,<:RingElement{â„›,T,<:HipVector}}, c2::CipherText{E,BFVParams}) where {E,â„›,T}

@@ -83,6 +83,8 @@ def lib():
         "tfhe_keyswitch": [vp, i32, i32, i32, vp, i32, vp, i32, vp, i64],
         "tfhe_rotate": [vp, i32, i32, i32, vp, i32, u64, vp, vp, i64],
         "tfhe_keyswitch_window": [vp, i32, i32, vp, i32, vp, i32, vp, i64],
+        "tfhe_ckks_encode": [vp, i32, u64, i32, vp, vp, i64],
+        "tfhe_ckks_decode": [vp, i32, u64, i32, vp, vp, i64],
         "tfhe_bfv_plan_create": [vp, i32p, i32, vp, i32p, i32, u64, C.POINTER(vp)],
         "tfhe_bfv_plan_destroy": [vp],
         "tfhe_bfv_plan_set_chunk": [vp, i32],
@@ -111,7 +113,7 @@ EXPORTED_SYMBOLS = [
     "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
     "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
     "tfhe_mul", "tfhe_mad", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
-    "tfhe_keyswitch", "tfhe_rotate", "tfhe_keyswitch_window", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
+    "tfhe_keyswitch", "tfhe_rotate", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
     "tfhe_bfv_plan_set_variant", "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
     "tfhe_event_create", "tfhe_event_destroy", "tfhe_event_record", "tfhe_event_elapsed_ms",
 ]
@@ -259,6 +261,12 @@ class Context:
 
     def keyswitch_window(self, level, window_bits, evk, n_windows, ct, polys, out, batch):
         check(lib().tfhe_keyswitch_window(self.h, level, window_bits, evk, n_windows, ct, polys, out, batch))
+
+    def ckks_encode(self, level, scale_mant, scale_exp2, slots, out, batch):
+        check(lib().tfhe_ckks_encode(self.h, level, int(scale_mant), int(scale_exp2), slots, out, batch))
+
+    def ckks_decode(self, level, scale_mant, scale_exp2, src, slots, batch):
+        check(lib().tfhe_ckks_decode(self.h, level, int(scale_mant), int(scale_exp2), src, slots, batch))
 
     def rotate(self, key_limbs, level, special, evk, n_digits, g, ct, out, batch):
         check(lib().tfhe_rotate(self.h, key_limbs, level, int(bool(special)), evk, n_digits, int(g), ct, out, batch))

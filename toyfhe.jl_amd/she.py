@@ -519,26 +519,52 @@ def modswitch(c: CipherText) -> CipherText:
 # --------------------------------------------------------------------------------------------------
 
 
+def scale_parts(scale):
+    """scale = mant * 2^exp2 with a 64-bit integer mant: exact for 2^k and for integers below 2^64 (times 2^k),
+    to 2^-63 relative otherwise (the boundary type of tfhe_ckks_encode / decode)."""
+    fr = Fraction(scale)
+    if fr <= 0:
+        raise AssertionError("scale must be positive")
+    num, den = fr.numerator, fr.denominator
+    if den & (den - 1) == 0:                               # dyadic: strip common powers of two
+        exp2 = -(den.bit_length() - 1)
+        while num % 2 == 0:
+            num //= 2; exp2 += 1
+        if num < 2**64:
+            return num, exp2
+    e = (num.bit_length() - den.bit_length()) - 63         # approximate: 63-64 significant bits
+    mant = int(round(fr / Fraction(2) ** e)) if e >= 0 else int(round(fr * Fraction(2) ** (-e)))
+    if mant >= 2**64:
+        mant //= 2; e += 1
+    return mant, e
+
+
 def ckks_encode(slots, ring: NegacyclicRing, scale) -> RingElement:
-    n2 = len(slots)
-    N, M = 2 * n2, 4 * n2
-    assert N == ring.N
-    cm = np.zeros(N, dtype=np.complex128)
-    for i in range(n2):
-        e = pow(3, i + 1, M)
-        cm[e >> 1] = slots[i]
-        cm[((M - e) % M) >> 1] = np.conj(slots[i])
-    ip = np.fft.ifft(cm)
-    tw = np.exp(1j * (np.arange(N) * 2 / (2 * N)) * np.pi)
-    real = (ip * tw).real
-    ints = [int(round(Fraction(float(x)) * Fraction(scale))) for x in real]  # round(BigInt, big(x)*denom), ckks.jl:42
-    return ring(ints)
+    """convert(RingElement, ::CKKSEncoding), ckksencoding.jl:72-97 -- on the device (tfhe_ckks_encode).
+    slots: [N/2] complex, or [batch][N/2]."""
+    z = np.ascontiguousarray(np.asarray(slots, dtype=np.complex128))
+    batch = None if z.ndim == 1 else z.shape[0]
+    z2 = z.reshape(-1, z.shape[-1])
+    if 2 * z2.shape[1] != ring.N:
+        raise AssertionError("CKKS plaintexts have N/2 slots")
+    if ring.idx != list(range(ring.L)):
+        raise UsageError("CKKS encoding: the ring must be a prefix of its context")
+    mant, exp2 = scale_parts(scale)
+    dz = DeviceBuffer.from_numpy(z2.view(np.uint64))
+    out = DeviceBuffer(z2.shape[0] * ring.L * ring.N)
+    ring.ctx.ckks_encode(ring.L, mant, exp2, dz.ptr, out.ptr, z2.shape[0])
+    ring.ctx.sync()
+    return RingElement(ring, out, None, batch)
 
 
 def ckks_decode(el: RingElement, scale) -> np.ndarray:
+    """CKKSEncoding{ScaleT}(plain), ckksencoding.jl:56-66 -- on the device (tfhe_ckks_decode)."""
     ring = el.ring
-    N, Q = ring.N, ring.modulus()
-    vals = np.array([float(Fraction(x - Q if x > Q // 2 else x) / Fraction(scale)) for x in el.to_ints()])
-    tw = np.exp(-1j * (np.arange(N) * 2 / (2 * N)) * np.pi)
-    f = np.fft.fft(vals * tw)
-    return f[[pow(3, c, 2 * N) >> 1 for c in range(1, N // 2 + 1)]]
+    if ring.idx != list(range(ring.L)):
+        raise UsageError("CKKS decoding: the ring must be a prefix of its context")
+    mant, exp2 = scale_parts(scale)
+    n = el.count
+    out = DeviceBuffer(n * ring.N)                         # N/2 complex doubles = N words per plaintext
+    ring.ctx.ckks_decode(ring.L, mant, exp2, el.coeffs_primal().ptr, out.ptr, n)
+    z = out.to_numpy().view(np.complex128).reshape(n, ring.N // 2)
+    return z if el.batch is not None else z[0]
