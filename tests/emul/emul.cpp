@@ -57,11 +57,11 @@ void block_inv_a(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
 static bool g_force_int = false;
 template <int LOGB>
 void block_fwd(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
-    if (L.Wd && x == 0 && !g_force_int) block_fwd_a<ArithFp, LOGB>(src, dst, L, x); else block_fwd_a<ArithInt, LOGB>(src, dst, L, x);
+    if (L.Wd && !g_force_int) block_fwd_a<ArithFp, LOGB>(src, dst, L, x); else block_fwd_a<ArithInt, LOGB>(src, dst, L, x);
 }
 template <int LOGB>
 void block_inv(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
-    if (L.Wd && x == 0 && !g_force_int) block_inv_a<ArithFp, LOGB>(src, dst, L, x); else block_inv_a<ArithInt, LOGB>(src, dst, L, x);
+    if (L.Wd && !g_force_int) block_inv_a<ArithFp, LOGB>(src, dst, L, x); else block_inv_a<ArithInt, LOGB>(src, dst, L, x);
 }
 
 template <int X>

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_block(const u64* __restri
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         if (item != blockIdx.x) __syncthreads();  // the previous item's last pass has read LDS
 #ifdef TFHE_FWD_PTW  // measured slower than the plain schedule for the forward transform (tools/ntt_ablate.hip)
-        if constexpr (A::whole_block_only)
+        if constexpr (A::prefetch_tw)
 #else
         if constexpr (false)
 #endif
@@ -184,12 +184,9 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restri
         }
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         if (item != blockIdx.x) __syncthreads();
-        if constexpr (A::whole_block_only) {  // the fp64 variant is only dispatched for x == 0
-#ifdef TFHE_NO_PTW
-            inv_schedule<A, LOGB, LOGT, LOGB, true>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, 0, 0u, addend);
-#else
-            inv_schedule_ptw<A, LOGB, LOGT, LOGB>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, addend, nullptr);
-#endif
+        if (A::prefetch_tw && x == 0) {  // fp64 policy, whole transform: 8-byte twiddles prefetched a pass ahead
+            if constexpr (A::prefetch_tw)
+                inv_schedule_ptw<A, LOGB, LOGT, LOGB>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, addend, nullptr);
         } else {
             if (x == 0)
                 inv_schedule<A, LOGB, LOGT, LOGB, true>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, 0, 0u, addend);

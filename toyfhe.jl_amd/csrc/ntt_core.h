@@ -132,7 +132,7 @@ TFHE_HD u64 lift_digit(u64 x, const lift_t& f) {
 // (q < TFHE_FP_QMAX), see fp64arith.h.
 // ---------------------------------------------------------------------------------------------
 struct ArithInt {
-    static constexpr bool whole_block_only = false;
+    static constexpr bool prefetch_tw = false;
     typedef u64 elem;
     typedef tw_t tw;
     struct ctx {
@@ -172,7 +172,7 @@ struct ArithInt {
 };
 
 struct ArithFp {
-    static constexpr bool whole_block_only = true;
+    static constexpr bool prefetch_tw = true;
     typedef double elem;
     typedef ftw_t tw;
     struct ctx {
@@ -606,7 +606,7 @@ TFHE_HD void ntt_fwd_top(const u64* src, u64* dst, const twd_t* W, u64 q, u64 co
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; r++) dst[col + (u64)r * stride] = v[r];  // lazy [0,4q): consumed by the block kernel
+    for (int r = 0; r < R; r++) dst[col + (u64)r * stride] = csub(csub(v[r], 2 * q), q);  // canonical: either block policy can take it
 }
 
 template <int X>

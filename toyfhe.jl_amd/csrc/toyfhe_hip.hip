@@ -122,7 +122,8 @@ void prof_end(tfhe_ctx* c) {
 }
 
 bool sel_fp(const tfhe_ctx* c, const limb_sel_t& sel, int x) {
-    if (x != 0 || c->variant == 2) return false;
+    (void)x;  // sub-blocks of N > 2^14 transforms use the same fp64 block kernels (top stages stay u64)
+    if (c->variant == 2) return false;
     for (int j = 0; j < sel.n; j++)
         if (!c->limbs_host[sel.idx[j]].Wd) return false;
     return true;
@@ -260,9 +261,9 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
         }
         prof_end(c);
         HIP_TRY(hipGetLastError());
-        return launch_block_fwd<ArithInt, 14>(c, t, dst, rows, sel, x, io);
+        return sel_fp(c, sel, x) ? launch_block_fwd<ArithFp, 14>(c, t, dst, rows, sel, x, io) : launch_block_fwd<ArithInt, 14>(c, t, dst, rows, sel, x, io);
     }
-    rc = launch_block_inv<ArithInt, 14>(c, src, t, rows, sel, x, io);
+    rc = sel_fp(c, sel, x) ? launch_block_inv<ArithFp, 14>(c, src, t, rows, sel, x, io) : launch_block_inv<ArithInt, 14>(c, src, t, rows, sel, x, io);
     if (rc) return rc;
     prof_begin(c, 0);
     switch (x) {
