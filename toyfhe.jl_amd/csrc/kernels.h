@@ -7,6 +7,8 @@
 #include "bfv_fast.h"
 #include "ntt_core.h"
 
+typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+
 struct limb_sel_t {  // which context modulus each buffer limb uses (crtselect, src/crt.jl:185-211)
     int n;
     int idx[TFHE_MAX_LIMBS];
@@ -375,6 +377,122 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_staged(const u64* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// N = 2^(LOGB+1) in ONE kernel (fp64 policy): the workgroup takes a whole row, does the top stage in registers and runs
+// the two 2^LOGB sub-blocks one after the other, holding the waiting half in registers (64 VGPRs) -- one read and one
+// write of the row instead of the extra pass of k_ntt_*_top plus strided block I/O.
+//   forward: a = lo + W[1] hi -> block 0,  b = lo - W[1] hi -> block 1; block outputs are interleaved in natural order
+//            (position 2 nat + sb).
+//   inverse: sub-block sb reads words 2 nat + sb; out_lo = (r0 + r1) N^-1, out_hi = (r0 - r1) W[1]^-1 N^-1.
+// ------------------------------------------------------------------------------------------------
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
+    static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass schedule expected");
+    typedef pgeom<LOGB, LOGT, K1 + K2, K3> G3;
+    constexpr int E = G3::E;
+    const u32 tid = threadIdx.x;
+    bool first = true;
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const typename A::ctx C = A::make(LT[sel.idx[item % (u32)sel.n]]);
+        const u64* s = src + ((size_t)item << (LOGB + 1));
+        u64* d = dst + ((size_t)item << (LOGB + 1));
+        u64 wa[E], wb[E];  // the two sub-blocks' first-pass operands (element bits)
+        {
+            const typename A::tw w1 = A::ld_fwd(C, 1u);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {  // two halves: bounds the raw operands in flight next to the 128 result registers
+#pragma unroll
+                for (int r = h * (E / 2); r < (h + 1) * (E / 2); r++) {
+                    const u32 j = tid + ((u32)r << LOGT);
+                    const double lo = fp_from_u64(s[j]);
+                    const double t = fp_mulmod_c(fp_from_u64(s[j + (1u << LOGB)]), w1, C.p, C.pinv);
+                    wa[r] = A::to_lds(fp_reduce(lo + t, C.p, C.pinv));
+                    wb[r] = A::to_lds(fp_reduce(lo - t, C.p, C.pinv));
+                }
+                TFHE_SCHED_FENCE();
+            }
+        }
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++) {
+            const u32 pre = 2u + (u32)sb;
+            if (!first) __syncthreads();  // the previous transform's last pass has read LDS
+            first = false;
+            {
+                typename A::elem v[E];
+                fwd_compute<A, LOGB, LOGT, 0, K1, false, false, 0>(v, sb ? wb : wa, nullptr, C, tid, pre);
+                fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+            }
+            __syncthreads();
+            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            __syncthreads();
+            {
+                u64 r3[E];
+                typename A::elem v[E];
+                fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
+                fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, pre);
+                // natural-order position 2 nat + sb: the two sub-blocks fill alternate words of the same lines (L2 merges them)
+                fwd_store<A, LOGB, LOGT, K1 + K2, K3, true>(v, lds, d, C, tid, 1, (u32)sb);
+            }
+        }
+    }
+}
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_pair(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_inv(LOGB, LOGT, LOGB), S1 = LOGB - K1;
+    typedef pgeom<LOGB, LOGT, S1, K1> G1;
+    constexpr int E = G1::E;
+    constexpr int K2 = pass_k_inv(LOGB, LOGT, S1), KL = S1 - K2;  // middle and last pass widths
+    static_assert(KL >= 1 && pass_k_inv(LOGB, LOGT, KL) == KL, "three-pass schedule expected");
+    const u32 tid = threadIdx.x;
+    bool first = true;
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const typename A::ctx C = A::make(LT[sel.idx[item % (u32)sel.n]]);
+        const u64* s = src + ((size_t)item << (LOGB + 1));
+        u64* d = dst + ((size_t)item << (LOGB + 1));
+        double res0[E];
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++) {
+            const u32 pre = 2u + (u32)sb;
+            if (!first) __syncthreads();
+            first = false;
+            {
+                u64 raw[E];  // sub-block sb = words 2 nat + sb of the row (the other sub-block's pass re-reads the lines from L2)
+                typename A::elem v[E];
+                inv_load_data<LOGB, LOGT, S1, K1, true>(raw, lds, s, tid, 1, (u32)sb);
+                inv_compute<A, LOGB, LOGT, S1, K1, true, false, 0>(v, raw, nullptr, C, tid, pre);
+                inv_store<A, LOGB, LOGT, S1, K1, true, false>(v, lds, nullptr, C, tid);
+            }
+            __syncthreads();
+            ntt_inv_pass<A, LOGB, LOGT, KL, K2, false, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            __syncthreads();
+            {
+                u64 r3[E];
+                typename A::elem v[E];
+                inv_load_data<LOGB, LOGT, 0, KL, false>(r3, lds, nullptr, tid, 0, 0u);
+                inv_compute<A, LOGB, LOGT, 0, KL, false, false, 0>(v, r3, nullptr, C, tid, pre);
+                if (sb == 0) {
+#pragma unroll
+                    for (int i = 0; i < E; i++) res0[i] = fp_reduce(v[i], C.p, C.pinv);
+                } else {  // top stage of the 2^(LOGB+1) transform with N^-1 folded in, then natural-order stores
+#pragma unroll
+                    for (int r = 0; r < E; r++) {
+                        const double y = fp_reduce(v[r], C.p, C.pinv);
+                        const double a = res0[r] + y, dd = res0[r] - y;
+                        const u32 j = tid + ((u32)r << LOGT);
+                        d[j] = fp_canon(fp_mulmod_c(a, C.ninv, C.p, C.pinv), C.p, C.pinv);
+                        d[j + (1u << LOGB)] = fp_canon(fp_mulmod_c(dd, C.w1n, C.p, C.pinv), C.p, C.pinv);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // top stages of N > 2^LOGB transforms: one column per thread, rows = count*limbs
 template <int X>
 __global__ __launch_bounds__(256) void k_ntt_fwd_top(const u64* __restrict__ src, u64* __restrict__ dst,
@@ -617,7 +735,6 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
 
 // Same sums for working moduli below 2^52, two coefficients per thread (16-byte loads / stores) and carry-free
 // 26-bit-split accumulation (modarith.h acc52): the kernel is bound by the digit stream, not by the multiplier.
-typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
 template <int DCH>
 __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk, const u64* __restrict__ dig,
                                                       u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
