@@ -136,6 +136,16 @@ int tfhe_keyswitch_window(tfhe_ctx *ctx, int level, int window_bits, const uint6
 int tfhe_ckks_encode(tfhe_ctx *ctx, int level, uint64_t scale_mant, int scale_exp2, const double *slots, uint64_t *out, int64_t batch);
 int tfhe_ckks_decode(tfhe_ctx *ctx, int level, uint64_t scale_mant, int scale_exp2, const uint64_t *in, double *slots, int64_t batch);
 
+/* ---- device-side samplers for RingSampler (poly.jl:7-23; RNS crt.jl:277-279) -- SURVEY §8(f) -------------------
+ * The ring is limbs 0..level-1 of ctx; out: [count][level][N], coefficient domain.  The random stream is Philox4x32-10
+ * keyed by `seed`, counter = (coefficient index of polynomial first_poly + p, attempt/limb, stream) -- defined in
+ * csrc/sample_kernels.h and restated in oracle/spec.py (Julia's generator cannot be matched).
+ *   uniform : independent exactly-uniform residues per limb (rejection sampling).
+ *   gaussian: multiplier * round(N(0, sigma^2)) (Box-Muller, ties to even), the same integer in every limb
+ *             (multiplier = 1 for BFV/CKKS noise and secrets, = t for BGV, bgv.jl:27-34). */
+int tfhe_sample_uniform(tfhe_ctx *ctx, int level, uint64_t seed, uint32_t stream, uint64_t first_poly, uint64_t *out, int64_t count);
+int tfhe_sample_gaussian(tfhe_ctx *ctx, int level, double sigma, uint64_t multiplier, uint64_t seed, uint32_t stream, uint64_t first_poly, uint64_t *out, int64_t count);
+
 /* ---- K12/K13: BFV multiplication (rlwe_she.jl:247-262 with bfv.jl:34-40,172-226) ---------------
  * plan = (ℛ = small ctx limbs idx_s, ℛbig = big ctx limbs idx_b, t).  Supported basis relations:
  * ℛbig ⊇ ℛ as sets of primes, or disjoint (test/bfv_crt.jl); anything else TFHE_E_UNSUPPORTED.

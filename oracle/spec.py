@@ -650,3 +650,45 @@ def ckks_decode(p, ring: Ring, scale):
     f = np.fft.fft(vals * tw)
     idx = [e >> 1 for e in zmstar_row1(2 * N, N // 2)]
     return f[idx]
+
+
+# --------------------------------------------------------------------------------------------
+# Samplers (poly.jl:7-23, crt.jl:277-279).  The reference draws from Julia's generator, which cannot be
+# reproduced here: PARITY UNPINNED for random streams.  What is pinned is the stream this build
+# DEFINES for its device samplers -- Philox4x32-10 (Salmon et al., SC'11; known-answer vectors from the
+# Random123 distribution in tests/test_oracle_known_answers.py) -- restated here for the GPU tests.
+# --------------------------------------------------------------------------------------------
+
+def philox4x32_10(c, k):
+    """counter c = 4 words, key k = 2 words (32-bit) -> 4 words"""
+    c0, c1, c2, c3 = c
+    k0, k1 = k
+    M = 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = (p1 >> 32) ^ c1 ^ k0, p1 & M, (p0 >> 32) ^ c3 ^ k1, p0 & M
+        k0, k1 = (k0 + 0x9E3779B9) & M, (k1 + 0xBB67AE85) & M
+    return c0, c1, c2, c3
+
+
+def sample_uniform_mod(idx: int, limb: int, stream: int, seed: int, q: int) -> int:
+    """csrc/sample_kernels.h sample_uniform_mod: rejection sampling on 64-bit draws"""
+    lim = ((2**64 - 1) // q) * q
+    a = 0
+    while True:
+        b = philox4x32_10((idx & 0xFFFFFFFF, idx >> 32, ((a << 8) | limb) & 0xFFFFFFFF, stream), (seed & 0xFFFFFFFF, seed >> 32))
+        for r in ((b[1] << 32) | b[0], (b[3] << 32) | b[2]):
+            if r < lim:
+                return r % q
+        a += 1
+
+
+def sample_gauss_int(idx: int, stream: int, seed: int, sigma: float) -> int:
+    """csrc/sample_kernels.h sample_gauss_int: Box-Muller, rint (ties to even)"""
+    import math
+    b = philox4x32_10((idx & 0xFFFFFFFF, idx >> 32, 0xFFFFFFFF, stream), (seed & 0xFFFFFFFF, seed >> 32))
+    r0, r1 = (b[1] << 32) | b[0], (b[3] << 32) | b[2]
+    u1, u2 = (float(r0 >> 11) + 1.0) * 2.0**-53, float(r1 >> 11) * 2.0**-53
+    z = math.sqrt(-2.0 * math.log(u1)) * math.cos(6.283185307179586476925286766559 * u2)
+    x = sigma * z
+    return int(round(x)) if abs(x - math.floor(x) - 0.5) > 1e-300 else int(2 * round(x / 2))

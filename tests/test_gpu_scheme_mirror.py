@@ -200,3 +200,56 @@ def test_ckks_mul_rescale_pipeline():
     assert res.ring().L == 2 and abs(res.scale - scale * scale / R.moduli[2]) < 1
     got = tf.ckks_decode(tf.decrypt(kp, res), res.scale)
     assert np.abs(got - a * b).max() < 1e-5
+
+
+def test_device_samplers_match_the_stream_definition():
+    """tfhe_sample_uniform bit-for-bit against oracle/spec.py's restatement of the Philox stream; the Gaussian sampler
+    agrees except where a last-place difference of log / cos flips the rounding, and has the right moments."""
+    N, qs = 256, chain(2**50 + 1, 2, 256) + chain(2**30 + 1, 1, 256)
+    ctx = tf.Context(N, qs)
+    seed, first, count = 0x1234567890ABCDEF, 5, 3
+    out = tf.DeviceBuffer(count * 3 * N)
+    ctx.sample_uniform(3, seed, 0, first, out.ptr, count)
+    got = out.to_numpy((count, 3, N))
+    for p in range(count):
+        for l, q in enumerate(qs):
+            want = [spec.sample_uniform_mod((first + p) * N + k, l, 0, seed, q) for k in range(N)]
+            assert [int(x) for x in got[p, l]] == want
+    assert all(int(got[:, l].max()) < q for l, q in enumerate(qs))
+    ctx.sample_gaussian(3, 3.2, 1, seed, 1, first, out.ptr, count)
+    g = out.to_numpy((count, 3, N))
+    want = np.array([[spec.sample_gauss_int((first + p) * N + k, 1, seed, 3.2) for k in range(N)] for p in range(count)])
+    cent = np.where(g[:, 0] > qs[0] // 2, g[:, 0].astype(np.int64) - qs[0], g[:, 0].astype(np.int64))
+    assert (cent != want).mean() < 0.01
+    for l, q in enumerate(qs):                                       # the same integer in every limb
+        assert np.array_equal(g[:, l], np.mod(cent, q).astype(np.uint64))
+    big = tf.DeviceBuffer(64 * 3 * N)
+    ctx.sample_gaussian(3, 3.2, 7, seed, 1, 100, big.ptr, 64)        # multiplier 7 (BGV-style t * e)
+    b = big.to_numpy((64, 3, N))[:, 2].astype(np.int64)
+    b = np.where(b > qs[2] // 2, b - qs[2], b)
+    assert np.all(b % 7 == 0)
+    e = b // 7
+    assert abs(e.mean()) < 0.1 and abs(e.std() - 3.2) < 0.1 and np.abs(e).max() < 30
+
+
+def test_keygen_encrypt_on_device_rng_and_wire_round_trip():
+    """keygen / encrypt with every random polynomial drawn on the GPU (DeviceRng), then the ciphertext through the
+    on-wire format and back."""
+    n = 1024
+    ch = chain(2**50 + 1, 5, n)
+    Rbig = tf.NegacyclicRing(n, ch)
+    R = Rbig.crtselect(range(2))
+    params = tf.BFVParams(R, Rbig, 65537)
+    rng = tf.DeviceRng(2024)
+    kp = tf.keygen(rng, params)
+    c = tf.encrypt(rng, kp, [[6] + [0] * (n - 1), [9] + [0] * (n - 1)])
+    assert [d[0] for d in tf.decrypt(kp, c)] == [6, 9]
+    blob = tf.she.dump_ciphertext(c)
+    c2 = tf.she.load_ciphertext(blob, params)
+    assert tf.she.dump_ciphertext(c2) == blob
+    prod = tf.keyswitch(tf.keygen_evalmult(rng, kp.priv), c2 * c2)
+    dec = tf.decrypt(kp, prod)
+    assert dec[0][0] == 36 and dec[1][0] == 81
+    # determinism: the same seed reproduces the same key material
+    kp_b = tf.keygen(tf.DeviceRng(2024), params)
+    assert np.array_equal(kp_b.priv.secret.to_numpy(), kp.priv.secret.to_numpy())

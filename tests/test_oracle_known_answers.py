@@ -109,3 +109,13 @@ def test_crtexpand_docstring():
     # crt.jl:42-58: CRTResidual(c) = c*[(q/q_i)^{-1}]_{q_i}*q/q_i; the docstring's arithmetic line
     # `mod(3*invmod(77, 5), 5)*77 == 308` is the (5,7,11) basis with c = 𝔽₅(3): residues (3,0,0)
     assert spec.rns_to_int([3, 0, 0], [5, 7, 11]) == 308 == (3 * pow(77, -1, 5) % 5) * 77
+
+
+def test_philox4x32_10_known_answers():
+    """Random123 kat_vectors (philox4x32, 10 rounds): the stream definition of the device samplers."""
+    from oracle import spec
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        assert spec.philox4x32_10(c, k) == want

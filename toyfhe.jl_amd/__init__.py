@@ -8,6 +8,7 @@ from . import native  # noqa: F401
 from .native import BfvPlan, Context, DeviceBuffer, Event, HipError, UsageError  # noqa: F401
 from . import ring, she  # noqa: F401,E402
 from .ring import NegacyclicRing, RingElement, nextprime  # noqa: F401,E402
-from .she import (BFVParams, BGVParams, CKKSParams, CipherText, ModulusRaised, apply_galois_element,  # noqa: F401,E402
+from . import wire  # noqa: F401,E402
+from .she import (DeviceRng, BFVParams, BGVParams, CKKSParams, CipherText, ModulusRaised, apply_galois_element,  # noqa: F401,E402
                   ckks_decode, ckks_encode, decrypt, enc_mul, encrypt, keygen, keygen_evalmult, keygen_galois,
                   keyswitch, make_eval_key, modswitch, rotate)

@@ -18,6 +18,7 @@
 #include "host_math.h"
 #include "kernels.h"
 #include "ckks_kernels.h"
+#include "sample_kernels.h"
 #include "ntt_tables.h"
 
 namespace {
@@ -874,6 +875,36 @@ int tfhe_ckks_decode(tfhe_ctx* c, int level, uint64_t scale_mant, int scale_exp2
                            (cplx_t*)slots + (size_t)b0 * (n / 2), (const u32*)c->ckks_gpos, n);
         HIP_TRY(hipGetLastError());
     }
+    return TFHE_OK;
+}
+
+// ---- device-side samplers (poly.jl:7-23, crt.jl:277-279; stream definition in sample_kernels.h) --------------------------
+int tfhe_sample_uniform(tfhe_ctx* c, int level, uint64_t seed, uint32_t stream, uint64_t first_poly, uint64_t* out, int64_t count) {
+    if (!c || !out) return fail(TFHE_E_BADARG, "null argument");
+    if (level < 1 || level > c->L) return fail(TFHE_E_LEVEL_MISMATCH, "level=%d outside [1,%d]", level, c->L);
+    if (count < 0) return fail(TFHE_E_BADARG, "negative count");
+    const u32 n = (u32)c->N;
+    for (int64_t p0 = 0; p0 < count; p0 += 32768) {
+        const unsigned np = (unsigned)std::min<int64_t>(32768, count - p0);
+        hipLaunchKernelGGL(k_sample_uniform, dim3((n + 255) / 256, (unsigned)level, np), dim3(256), 0, c->stream, out + (size_t)p0 * level * n,
+                           c->limbs_dev, level, seed, stream, n, first_poly + (u64)p0);
+    }
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+int tfhe_sample_gaussian(tfhe_ctx* c, int level, double sigma, uint64_t multiplier, uint64_t seed, uint32_t stream, uint64_t first_poly,
+                         uint64_t* out, int64_t count) {
+    if (!c || !out) return fail(TFHE_E_BADARG, "null argument");
+    if (level < 1 || level > c->L) return fail(TFHE_E_LEVEL_MISMATCH, "level=%d outside [1,%d]", level, c->L);
+    if (!(sigma >= 0) || sigma > 1e15) return fail(TFHE_E_BADARG, "sigma out of range");
+    if (count < 0) return fail(TFHE_E_BADARG, "negative count");
+    const u32 n = (u32)c->N;
+    for (int64_t p0 = 0; p0 < count; p0 += 32768) {
+        const unsigned np = (unsigned)std::min<int64_t>(32768, count - p0);
+        hipLaunchKernelGGL(k_sample_gaussian, dim3((n + 255) / 256, np), dim3(256), 0, c->stream, out + (size_t)p0 * level * n, c->limbs_dev,
+                           level, sigma, multiplier, seed, stream, n, first_poly + (u64)p0);
+    }
+    HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
 

@@ -83,6 +83,8 @@ def lib():
         "tfhe_keyswitch": [vp, i32, i32, i32, vp, i32, vp, i32, vp, i64],
         "tfhe_rotate": [vp, i32, i32, i32, vp, i32, u64, vp, vp, i64],
         "tfhe_keyswitch_window": [vp, i32, i32, vp, i32, vp, i32, vp, i64],
+        "tfhe_sample_uniform": [vp, i32, u64, C.c_uint32, u64, vp, i64],
+        "tfhe_sample_gaussian": [vp, i32, C.c_double, u64, u64, C.c_uint32, u64, vp, i64],
         "tfhe_ckks_encode": [vp, i32, u64, i32, vp, vp, i64],
         "tfhe_ckks_decode": [vp, i32, u64, i32, vp, vp, i64],
         "tfhe_bfv_plan_create": [vp, i32p, i32, vp, i32p, i32, u64, C.POINTER(vp)],
@@ -113,7 +115,7 @@ EXPORTED_SYMBOLS = [
     "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
     "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
     "tfhe_mul", "tfhe_mad", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
-    "tfhe_keyswitch", "tfhe_rotate", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
+    "tfhe_keyswitch", "tfhe_rotate", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
     "tfhe_bfv_plan_set_variant", "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
     "tfhe_event_create", "tfhe_event_destroy", "tfhe_event_record", "tfhe_event_elapsed_ms",
 ]
@@ -261,6 +263,12 @@ class Context:
 
     def keyswitch_window(self, level, window_bits, evk, n_windows, ct, polys, out, batch):
         check(lib().tfhe_keyswitch_window(self.h, level, window_bits, evk, n_windows, ct, polys, out, batch))
+
+    def sample_uniform(self, level, seed, stream, first_poly, out, count):
+        check(lib().tfhe_sample_uniform(self.h, level, int(seed), int(stream), int(first_poly), out, count))
+
+    def sample_gaussian(self, level, sigma, multiplier, seed, stream, first_poly, out, count):
+        check(lib().tfhe_sample_gaussian(self.h, level, float(sigma), int(multiplier), int(seed), int(stream), int(first_poly), out, count))
 
     def ckks_encode(self, level, scale_mant, scale_exp2, slots, out, batch):
         check(lib().tfhe_ckks_encode(self.h, level, int(scale_mant), int(scale_exp2), slots, out, batch))

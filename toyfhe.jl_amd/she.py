@@ -27,10 +27,47 @@ from .ring import NegacyclicRing, RingElement
 # --------------------------------------------------------------------------------------------------
 
 
-def sample_uniform(rng: np.random.Generator, ring: NegacyclicRing, batch=None) -> RingElement:
+class DeviceRng:
+    """Counter-based generator for the device samplers (tfhe_sample_uniform / tfhe_sample_gaussian): Philox4x32-10 keyed by
+    `seed`; every draw of a polynomial advances the polynomial counter, every sampler call site its own stream id.
+    Passing a DeviceRng where the mirror takes an `rng` makes keygen / encrypt sample on the GPU (no host round trip)."""
+
+    def __init__(self, seed: int):
+        self.seed, self.next_poly = int(seed) & (2**64 - 1), 0
+
+    def take(self, n: int) -> int:
+        first, self.next_poly = self.next_poly, self.next_poly + n
+        return first
+
+
+def _device_sample(rng: DeviceRng, ring: NegacyclicRing, batch, gaussian=None):
+    if ring.idx != list(range(ring.L)):
+        raise UsageError("device sampling: the ring must be a prefix of its context")
+    n = 1 if batch is None else int(batch)
+    out = DeviceBuffer(n * ring.L * ring.N)
+    first = rng.take(n)
+    if gaussian is None:
+        ring.ctx.sample_uniform(ring.L, rng.seed, 0, first, out.ptr, n)
+    else:
+        sigma, mult = gaussian
+        ring.ctx.sample_gaussian(ring.L, sigma, mult, rng.seed, 1, first, out.ptr, n)
+    return RingElement(ring, out, None, batch)
+
+
+def sample_uniform(rng, ring: NegacyclicRing, batch=None) -> RingElement:
+    """RingSampler(ℛ, DiscreteUniform(coefftype)), poly.jl:7-23 / crt.jl:146-148,277-279: limb-wise independent."""
+    if isinstance(rng, DeviceRng):
+        return _device_sample(rng, ring, batch)
     shape = (ring.N,) if batch is None else (batch, ring.N)
     cols = [rng.integers(0, q, size=shape, dtype=np.uint64) for q in ring.moduli]
     return RingElement.from_host(ring, np.stack(cols, axis=len(shape) - 1))
+
+
+def sample_noise(rng, ring: NegacyclicRing, sigma: float, batch=None, scale: int = 1) -> RingElement:
+    """scale * round(N(0, sigma^2)) coefficients (𝒩 / 𝒢 of the schemes; rounded Gaussian as in test/bfv_crt.jl:34)."""
+    if isinstance(rng, DeviceRng):
+        return _device_sample(rng, ring, batch, gaussian=(sigma, scale))
+    return lift_ints(ring, sample_normal_ints(rng, ring.N, sigma, batch), scale)
 
 
 def sample_normal_ints(rng: np.random.Generator, N: int, sigma: float, batch=None):
@@ -59,10 +96,10 @@ class SHESchemeParams:
         return self.R_cipher()
 
     def noise(self, rng, ring, batch=None):  # 𝒩
-        return lift_ints(ring, sample_normal_ints(rng, ring.N, self.sigma, batch))
+        return sample_noise(rng, ring, self.sigma, batch)
 
     def secret_dist(self, rng, ring, batch=None):  # 𝒢
-        return lift_ints(ring, sample_normal_ints(rng, ring.N, self.sigma, batch))
+        return sample_noise(rng, ring, self.sigma, batch)
 
     def mul_expand(self, c):                 # rlwe_she.jl:39
         return None
@@ -120,7 +157,7 @@ class BGVParams(SHESchemeParams):
         return self.ring
 
     def noise(self, rng, ring, batch=None):  # ShiftedDiscreteNormal, bgv.jl:27-34
-        return lift_ints(ring, sample_normal_ints(rng, ring.N, self.sigma, batch), self.t)
+        return sample_noise(rng, ring, self.sigma, batch, self.t)
 
     def encode(self, plain):
         return self.ring(_map_plain(plain, lambda m: int(m) % self.t))
@@ -568,3 +605,36 @@ def ckks_decode(el: RingElement, scale) -> np.ndarray:
     ring.ctx.ckks_decode(ring.L, mant, exp2, el.coeffs_primal().ptr, out.ptr, n)
     z = out.to_numpy().view(np.complex128).reshape(n, ring.N // 2)
     return z if el.batch is not None else z[0]
+
+
+# --------------------------------------------------------------------------------------------------
+# on-wire format (wire.py): device <-> bytes
+# --------------------------------------------------------------------------------------------------
+
+def dump_ciphertext(c: CipherText) -> bytes:
+    """CipherText -> wire blob (coefficient domain, [count][polys][L][N])."""
+    from . import wire
+    ring = c[0].ring
+    res = np.stack([x.to_numpy("primal").reshape(x.count, ring.L, ring.N) for x in c.cs], axis=1)
+    scale = scale_parts(c.scale) if c.scale is not None else (0, 0)
+    return wire.dump(res, ring.moduli, ring.psi, kind=wire.KIND_CIPHERTEXT, domain=0, scale=scale)
+
+
+def load_ciphertext(blob: bytes, params) -> CipherText:
+    """wire blob -> CipherText on the device; the ring (moduli, psi) must be the scheme's ciphertext ring at that level."""
+    from . import wire
+    d = wire.load(blob)
+    if d["kind"] != wire.KIND_CIPHERTEXT or d["domain"] != 0:
+        raise UsageError("not a coefficient-domain ciphertext blob")
+    ring = params.R_cipher()
+    L = len(d["moduli"])
+    if L != ring.L:
+        ring = ring.crtselect(range(L))
+    if d["N"] != ring.N or d["moduli"] != list(ring.moduli) or d["psis"] != list(ring.psi):
+        raise UsageError("blob ring does not match the parameters' ciphertext ring")
+    res = d["residues"]
+    batch = res.shape[0]
+    cs = [RingElement.from_host(ring, res[:, p]) for p in range(d["polys"])]
+    smant, sexp = d["scale"]
+    scale = None if smant == 0 else Fraction(smant) * Fraction(2) ** sexp
+    return CipherText(params, cs, scale)
