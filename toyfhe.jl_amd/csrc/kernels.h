@@ -616,19 +616,36 @@ __global__ __launch_bounds__(256) void k_tensor(const u64* __restrict__ a, const
     const u64 *a0 = a + (size_t)ct * 2 * ps + (size_t)j * n, *a1 = a0 + ps;
     const u64 *b0 = b + (size_t)ct * 2 * ps + (size_t)j * n, *b1 = b0 + ps;
     u64 *o0 = out + (size_t)ct * 3 * ps + (size_t)j * n, *o1 = o0 + ps, *o2 = o1 + ps;
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
-        const u64 x0 = a0[i], x1 = a1[i], y0 = b0[i], y1 = b1[i];
-        o0[i] = mulmod(x0, y0, L.br);
+    auto one = [&](u64 x0, u64 x1, u64 y0, u64 y1, u64& r0, u64& r1, u64& r2) {
+        r0 = mulmod(x0, y0, L.br);
         acc128 acc{0, 0};
         acc_mac(acc, x0, y1);
         if (L.br.sh <= 58) {  // two products fit the Barrett window when q < 2^61
             acc_mac(acc, x1, y0);
-            o1[i] = barrett_reduce128(acc.lo, acc.hi, L.br);
+            r1 = barrett_reduce128(acc.lo, acc.hi, L.br);
         } else {
-            o1[i] = addmod(barrett_reduce128(acc.lo, acc.hi, L.br), mulmod(x1, y0, L.br), L.q);
+            r1 = addmod(barrett_reduce128(acc.lo, acc.hi, L.br), mulmod(x1, y0, L.br), L.q);
         }
-        o2[i] = mulmod(x1, y1, L.br);
+        r2 = mulmod(x1, y1, L.br);
+    };
+    if ((n & 1u) == 0) {  // two coefficients per thread: 16-byte loads and stores
+        for (u32 i = threadIdx.x * 2; i < n; i += blockDim.x * 2) {
+            const u64x2_t x0 = *(const u64x2_t*)(a0 + i), x1 = *(const u64x2_t*)(a1 + i);
+            const u64x2_t y0 = *(const u64x2_t*)(b0 + i), y1 = *(const u64x2_t*)(b1 + i);
+            u64x2_t r0, r1, r2;
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                u64 t0, t1, t2;
+                one(x0[v], x1[v], y0[v], y1[v], t0, t1, t2);
+                r0[v] = t0; r1[v] = t1; r2[v] = t2;
+            }
+            *(u64x2_t*)(o0 + i) = r0;
+            *(u64x2_t*)(o1 + i) = r1;
+            *(u64x2_t*)(o2 + i) = r2;
+        }
+        return;
     }
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) one(a0[i], a1[i], b0[i], b1[i], o0[i], o1[i], o2[i]);
 }
 
 // modswitch (crt.jl:215-228): rows = count*(limbs-1)
