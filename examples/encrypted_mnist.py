@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Encrypted CNN inference in the shape of the reference's examples/encrypted_mnist/infer.jl,
+driven through the host mirror with every ring operation on the MI355X.
+
+The reference evaluates a trained Flux model (mnist_conv.bson) on MNIST; neither the weights (BSON, needs Julia) nor
+the dataset are available here, so this script draws a model of the same architecture and a batch of synthetic 28x28
+images from a seeded generator and checks the homomorphic result against the same arithmetic in float64
+(infer.jl:55-88 `do_encrypted_inference`):
+
+    conv 7x7 stride 3, 4 channels (49 ciphertexts x plaintext scalars)  ->  + bias  ->  rescale        infer.jl:127-131
+    square + relinearise + rescale                                                                      :136-138
+    dense 256 -> 64 as 4 diagonal-packed 64x64 products (63 rotations by 64 slots each)  + bias, rescale :142-165
+    square + relinearise + rescale                                                                      :167-169
+    dense 64 -> 10 (zero-padded to 64x64, 63 rotations) + bias                                          :171-179
+
+Packing: N/2 slots = 64 windows x B images (B = N/128; the reference uses N = 2^13, B = 64), slot = window * B + image.
+
+  python examples/encrypted_mnist.py [--logn 13] [--seed 0]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import toyfhe_jl_amd as tf  # noqa: E402
+
+
+def public_preprocess(batch):
+    """infer.jl:57-64: I[i][j] = matrix [image k][window l] of pixel (i, j) of each 7x7 window (stride 3, 8x8 windows)"""
+    B = batch.shape[0]
+    I = np.empty((7, 7, B, 64))
+    for a in range(8):
+        for b in range(8):
+            I[:, :, :, a + 8 * b] = batch[:, a * 3:a * 3 + 7, b * 3:b * 3 + 7].transpose(1, 2, 0)
+    return I
+
+
+def plain_matmul(W, x):
+    """infer.jl:44-46 on plaintext: sum_k diag(circshift(W, (0, k-1))) .* circshift(x, (k-1, 0)) == W @ x"""
+    n = x.shape[0]
+    out = np.zeros_like(x)
+    for k in range(n):
+        d = np.array([W[i, (i - k) % n] for i in range(n)])
+        out += d[:, None] * np.roll(x, k, axis=0)
+    return out
+
+
+def plain_model(model, batch):
+    I = public_preprocess(batch)                                   # [7][7][B][64]
+    conv = [sum(I[i, j] * model["conv_w"][i, j, ch] for i in range(7) for j in range(7)) + model["conv_b"][ch] for ch in range(4)]
+    sq1 = [(c ** 2).T for c in conv]                               # [64 windows][B]
+    fq1 = sum(plain_matmul(model["fq1_w"][:, 64 * i:64 * (i + 1)], sq1[i]) for i in range(4)) + model["fq1_b"][:, None]
+    sq2 = fq1 ** 2
+    W2 = np.vstack([model["fq2_w"], np.zeros((54, 64))])
+    return (plain_matmul(W2, sq2) + np.concatenate([model["fq2_b"], np.zeros(54)])[:, None])[:10]
+
+
+def encrypted_matmul(gk, W, x, B):
+    """infer.jl:140-149: diagonal method; `rotate` by B slots moves every window's value to the next window"""
+    n = 64
+    diag = lambda k: np.repeat(np.array([W[i, (i - k) % n] for i in range(n)]), B)
+    result = x.mul_plain(diag(0))
+    rotated = x
+    for k in range(1, n):
+        rotated = tf.rotate(gk, rotated)
+        result = result + rotated.mul_plain(diag(k))
+    return result
+
+
+def run(logn=13, seed=0, verbose=True):
+    N = 1 << logn
+    B = N // 128                                                   # images per ciphertext
+    rs = np.random.default_rng(seed)
+    model = {"conv_w": rs.normal(0, 0.15, (7, 7, 4)), "conv_b": rs.normal(0, 0.1, 4),
+             "fq1_w": rs.normal(0, 0.06, (64, 256)), "fq1_b": rs.normal(0, 0.1, 64),
+             "fq2_w": rs.normal(0, 0.1, (10, 64)), "fq2_b": rs.normal(0, 0.1, 10)}
+    batch = rs.random((B, 28, 28))
+    want = plain_model(model, batch)
+
+    # infer.jl:97-112: q0 (60 bit), five 40-bit primes, 60-bit special prime; ModulusRaised CKKS, sigma 3.2
+    q0 = tf.nextprime(2**60 + 1, 1, 2 * N)
+    ps = tf.nextprime(q0 + 2 * N, 1, 2 * N)
+    qs = [tf.nextprime(2**40 + 1, 1, 2 * N)]
+    for _ in range(4):
+        qs.append(tf.nextprime(qs[-1] + 2 * N, 1, 2 * N))
+    ring = tf.NegacyclicRing(N, [q0] + qs + [ps])
+    params = tf.ModulusRaised(tf.CKKSParams(ring, 0, 3.2))
+    rng = tf.DeviceRng(seed + 1)                                   # all sampling on the GPU
+    t0 = time.perf_counter()
+    kp = tf.keygen(rng, params)
+    ek = tf.keygen_evalmult(rng, kp.priv)
+    gk = tf.keygen_galois(rng, kp.priv, steps=B)                   # infer.jl:134 (steps = 64 there)
+    scale = 2**40
+    I = public_preprocess(batch)
+    cring = params.R_cipher()
+    C = [[tf.encrypt(rng, kp, tf.ckks_encode(I[i, j].T.reshape(-1), cring, scale), scale=scale) for j in range(7)] for i in range(7)]
+    t_setup = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    conved = []
+    for ch in range(4):
+        acc = None
+        for i in range(7):
+            for j in range(7):
+                term = C[i][j].mul_plain(float(model["conv_w"][i, j, ch]))
+                acc = term if acc is None else acc + term
+        conved.append(tf.modswitch(acc.add_plain(float(model["conv_b"][ch]))))
+    sq1 = [tf.modswitch(tf.keyswitch(ek, c * c)) for c in conved]
+    fq1 = None
+    for i in range(4):
+        part = encrypted_matmul(gk, model["fq1_w"][:, 64 * i:64 * (i + 1)], sq1[i], B)
+        fq1 = part if fq1 is None else fq1 + part
+    fq1 = tf.modswitch(fq1.add_plain(np.repeat(model["fq1_b"], B)))
+    sq2 = tf.modswitch(tf.keyswitch(ek, fq1 * fq1))
+    W2 = np.vstack([model["fq2_w"], np.zeros((54, 64))])
+    res = encrypted_matmul(gk, W2, sq2, B).add_plain(np.repeat(np.concatenate([model["fq2_b"], np.zeros(54)]), B))
+    got = tf.ckks_decode(tf.decrypt(kp, res), res.scale).real.reshape(64, B)[:10]
+    t_eval = time.perf_counter() - t0
+    err = float(np.abs(got - want).max())
+    if verbose:
+        print(f"N=2^{logn}, {B} images per ciphertext: setup {t_setup:.1f} s, encrypted evaluation {t_eval:.1f} s "
+              f"(49 encrypted inputs, 5 x 63 rotations, 5 relinearisations)")
+        print(f"max |encrypted - plaintext| over the 10 x {B} logits: {err:.3e}   (logit range +-{np.abs(want).max():.2f})")
+        print("argmax agreement:", float((got.argmax(0) == want.argmax(0)).mean()))
+    return err, float(np.abs(want).max())
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--logn", type=int, default=13)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    run(a.logn, a.seed)

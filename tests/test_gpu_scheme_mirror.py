@@ -253,3 +253,15 @@ def test_keygen_encrypt_on_device_rng_and_wire_round_trip():
     # determinism: the same seed reproduces the same key material
     kp_b = tf.keygen(tf.DeviceRng(2024), params)
     assert np.array_equal(kp_b.priv.secret.to_numpy(), kp.priv.secret.to_numpy())
+
+
+def test_encrypted_cnn_inference_pipeline():
+    """examples/encrypted_mnist.py (the shape of the reference's examples/encrypted_mnist/infer.jl: 49 encrypted inputs,
+    plaintext-scalar / plaintext-vector products, 5 relinearisations, 5 x 63 rotations, 5 rescales) at N = 2^11 with a
+    synthetic model, against the same arithmetic in float64."""
+    import importlib.util, os
+    spec_ = importlib.util.spec_from_file_location("encrypted_mnist", os.path.join(os.path.dirname(__file__), "..", "examples", "encrypted_mnist.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    err, rng_ = mod.run(logn=11, seed=3, verbose=False)
+    assert err < 1e-4 * max(1.0, rng_), err

@@ -332,7 +332,39 @@ class CipherText:
             return CipherText(self.params, enc_mul(self, o), scale)
         if isinstance(o, int):
             return CipherText(self.params, [c * o for c in self.cs], self.scale)
+        if isinstance(o, float):                     # ct * b::AbstractFloat, ckksencoding.jl:99-102
+            return self.mul_plain(o)
         raise TypeError(type(o))
+
+    __rmul__ = __mul__
+
+    # ---- CKKS plaintext operands (ckksencoding.jl:99-124); the ciphertext carries its scale ----
+    def _need_scale(self):
+        if self.scale is None:
+            raise UsageError("plaintext operands need a CKKS ciphertext (with a scale)")
+
+    def mul_plain(self, x) -> "CipherText":
+        """ct * float (:99-102) or vector .* ct (:104-109): the operand is brought to the ciphertext's scale, every
+        component is multiplied by it; the result's scale is the square."""
+        self._need_scale()
+        if np.isscalar(x):
+            fr = Fraction(float(x)) * Fraction(self.scale)
+            fl = fr.numerator // fr.denominator
+            rem = fr - fl
+            scaled = fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2) else 0)   # FixedRational(b).x, ckks.jl:42
+            cs = [c * int(scaled) for c in self.cs]
+        else:
+            re = ckks_encode(np.asarray(x, dtype=np.complex128), self.ring(), self.scale)
+            cs = [c * re for c in self.cs]
+        return CipherText(self.params, cs, Fraction(self.scale) ** 2)
+
+    def add_plain(self, x) -> "CipherText":
+        """ct .+ float / ct .+ vector (:111-124): encoded at the ciphertext's scale and added to the first component."""
+        self._need_scale()
+        n2 = self.ring().N // 2
+        v = np.full(n2, x, dtype=np.complex128) if np.isscalar(x) else np.asarray(x, dtype=np.complex128)
+        re = ckks_encode(v, self.ring(), self.scale)
+        return CipherText(self.params, (self.cs[0] + re,) + self.cs[1:], self.scale)
 
 
 # --------------------------------------------------------------------------------------------------
