@@ -75,7 +75,6 @@ int main(int argc, char** argv) {
         LT[l].Wb = (twd_t*)up(HT.Wb.data(), N * 16); LT[l].Winvb = (twd_t*)up(HT.Wib.data(), N * 16);
         LT[l].Wd = (ftwd_t*)up(HT.Wd.data(), N * 8); LT[l].Winvd = (ftwd_t*)up(HT.Wid.data(), N * 8);
         LT[l].Wdb = (ftwd_t*)up(HT.Wdb.data(), N * 8); LT[l].Winvdb = (ftwd_t*)up(HT.Widb.data(), N * 8);
-        LT[l].Wbs = (twd_t*)up(HT.Wbs.data(), N * 16); LT[l].Wdbs = (ftwd_t*)up(HT.Wdbs.data(), N * 8);
     }
     ntt_limb_t* dLT; hipMalloc(&dLT, L * sizeof(ntt_limb_t)); hipMemcpy(dLT, LT.data(), L * sizeof(ntt_limb_t), hipMemcpyHostToDevice);
     u64 *d_a, *d_b; hipMalloc(&d_a, (size_t)rows * N * 8); hipMalloc(&d_b, (size_t)rows * N * 8);

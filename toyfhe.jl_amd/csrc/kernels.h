@@ -31,30 +31,9 @@ __device__ __forceinline__ void fwd_schedule(u64* lds, const u64* gsrc, u64* gds
         fwd_schedule<A, LOGB, LOGT, S0 + K>(lds, gsrc, gdst, C, tid, pre, x, sbrev, lift);
     }
 }
-// ---- same, with the twiddles of pass p+1 requested before the LDS exchange that ends pass p (8-byte fp64 twiddles:
-// a whole pass's set fits the register budget of a 512-thread workgroup) ----
-template <class A, int LOGB, int LOGT, int S0>
-__device__ __forceinline__ void fwd_schedule_ptw(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
-                                                 u32 pre, const lift_t* lift, const typename A::tw* tw_cur) {
-    constexpr int K = pass_k_fwd(LOGB, LOGT, S0);
-    constexpr bool FIRST = (S0 == 0), LAST = (S0 + K == LOGB);
-    typedef pgeom<LOGB, LOGT, S0, K> G;
-    u64 raw[G::E];
-    typename A::elem v[G::E];
-    fwd_load_data<LOGB, LOGT, S0, K, FIRST, LAST>(raw, lds, gsrc, tid);
-    fwd_compute<A, LOGB, LOGT, S0, K, FIRST, LAST, FIRST ? 0 : K>(v, raw, tw_cur, C, tid, pre, FIRST ? lift : nullptr);
-    if constexpr (!LAST) {
-        constexpr int K2 = pass_k_fwd(LOGB, LOGT, S0 + K);
-        typedef pgeom<LOGB, LOGT, S0 + K, K2> G2;
-        typename A::tw tw_next[G2::SETS * G2::NTW];
-        fwd_load_tw<A, LOGB, LOGT, S0 + K, K2, (S0 + K + K2 == LOGB)>(tw_next, C, tid, pre);
-        fwd_store<A, LOGB, LOGT, S0, K, false>(v, lds, gdst, C, tid, 0, 0u);
-        __syncthreads();
-        fwd_schedule_ptw<A, LOGB, LOGT, S0 + K>(lds, gsrc, gdst, C, tid, pre, lift, tw_next);
-    } else {
-        fwd_store<A, LOGB, LOGT, S0, K, true>(v, lds, gdst, C, tid, 0, 0u);
-    }
-}
+// ---- inverse schedule with the twiddles of pass p+1 requested before the LDS exchange that ends pass p (8-byte fp64
+// twiddles: a whole pass's set fits the register budget of a 512-thread workgroup).  +9 % for the inverse transform; the
+// same idea measured slower for the forward one, which keeps the simple schedule. ----
 template <class A, int LOGB, int LOGT, int SEND>
 __device__ __forceinline__ void inv_schedule_ptw(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
                                                  u32 pre, const u64* addend, const typename A::tw* tw_cur) {
@@ -117,15 +96,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_block(const u64* __restri
         }
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         if (item != blockIdx.x) __syncthreads();  // the previous item's last pass has read LDS
-#ifdef TFHE_FWD_PTW  // measured slower than the plain schedule for the forward transform (tools/ntt_ablate.hip)
-        if constexpr (A::prefetch_tw)
-#else
-        if constexpr (false)
-#endif
-            fwd_schedule_ptw<A, LOGB, LOGT, 0>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, lift, nullptr);
-        else
-            fwd_schedule<A, LOGB, LOGT, 0>(lds, src + srow * ntot + ((size_t)sb << LOGB), dst + drow * ntot, C, threadIdx.x,
-                                           (1u << x) + sb, x, brev_bits(sb, x), lift);
+        fwd_schedule<A, LOGB, LOGT, 0>(lds, src + srow * ntot + ((size_t)sb << LOGB), dst + drow * ntot, C, threadIdx.x,
+                                       (1u << x) + sb, x, brev_bits(sb, x), lift);
     }
 }
 // Digit-lift forward transforms of the key switch (ntt_io_t mode 1) with the source row read ONCE: item = (ciphertext b,

@@ -106,8 +106,6 @@ struct ntt_limb_t {   // per-limb constants (device copy lives in the context)
     const ftwd_t* Winvdb;
     // same idea for the split kernels (a 2^14 transform as two 2^13 half-problems, see k_ntt_fwd_split14): the
     // boundary pass of each half permuted within its half of every stage block
-    const twd_t* Wbs;
-    const ftwd_t* Wdbs;
 };
 
 // Progress hook of the butterfly loops: called after every twiddle group with the number of butterflies of the
@@ -141,12 +139,6 @@ struct ArithInt {
         tw_t ninv, w1n;
     };
     static TFHE_HD ctx make(const ntt_limb_t& L) { return ctx{L.q, L.W, L.Winv, L.Wb, L.Winvb, L.ninv, L.w1inv_ninv}; }
-    static TFHE_HD ctx make_split(const ntt_limb_t& L) { return ctx{L.q, L.W, L.Winv, L.Wbs, nullptr, L.ninv, L.w1inv_ninv}; }
-    // top stage of a split transform: lo +/- W[1]*hi, result in the policy's lazy range
-    static TFHE_HD elem top_stage(u64 lo, u64 hi, u32 sb, const ctx& c) {
-        const u64 t = shoup_lazy(hi, ld_tw(c.W, 1), c.q);  // [0,2q)
-        return sb ? lo + 2 * c.q - t : lo + t;              // < 3q, inside the forward range [0,4q)
-    }
     static TFHE_HD tw ld_fwd_b(const ctx& c, u32 i) { return ld_tw(c.Wb, i); }
     static TFHE_HD tw ld_inv_b(const ctx& c, u32 i) { return ld_tw(c.Winvb, i); }
     static TFHE_HD bool has_b(const ctx& c) { return c.Wb != nullptr; }
@@ -183,13 +175,6 @@ struct ArithFp {
     };
     static TFHE_HD ctx make(const ntt_limb_t& L) {
         return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.Wdb, L.Winvdb, L.ninv_d, L.w1inv_ninv_d, L.q};
-    }
-    static TFHE_HD ctx make_split(const ntt_limb_t& L) {
-        return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.Wdbs, nullptr, L.ninv_d, L.w1inv_ninv_d, L.q};
-    }
-    static TFHE_HD elem top_stage(u64 lo, u64 hi, u32 sb, const ctx& c) {
-        const double a = from_global(lo, c), t = fp_mulmod_c(from_global(hi, c), ld(c.W, 1), c.p, c.pinv);
-        return fp_reduce(sb ? a - t : a + t, c.p, c.pinv);
     }
     // centred representative: keeps |v| <= p/2 at the start of the first pass (range budget of a 5-stage pass)
     static TFHE_HD elem from_global(u64 x, const ctx& c) {
@@ -285,11 +270,7 @@ struct pgeom {
         const u32 c = BREV ? brev_bits(c0, LOGB - K) : c0;
         const u32 lo = c & ((1u << LO) - 1);
         // one register set and LO >= LOGT: c = tid < 2^LO, so the twiddle index is workgroup-uniform (scalar loads)
-#ifdef TFHE_NO_UNIFORM_HI
-        hi = c >> LO;
-#else
         hi = (!BREV && SETS == 1 && LO >= LOGT) ? 0u : c >> LO;
-#endif
         base = (hi << (LOGB - S0)) + lo;
     }
 };
@@ -329,29 +310,17 @@ TFHE_HD void fwd_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, c
             raw[u * G::R + r] = FIRST ? gsrc[j] : lds[pb + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)];
         }
     }
-#ifndef TFHE_NO_LOADFENCE
     TFHE_SCHED_FENCE();  // every operand is requested before the first butterfly (no just-in-time read/wait pairs)
-#endif
     (void)lift;
 }
 // Butterflies of the pass.  Twiddles of stages d < PF come from `twp` (requested ahead by the caller);
 // the others are loaded here (the compiler schedules those loads).
-template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int PF, int USEL = -1, bool SPLIT = false,
-          class HOOK = no_hook>
+template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int PF, int USEL = -1, class HOOK = no_hook>
 TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
-                         u32 pre, const lift_t* lift = nullptr, const u64* raw_hi = nullptr, const HOOK& hook = HOOK()) {
+                         u32 pre, const lift_t* lift = nullptr, const HOOK& hook = HOOK()) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
-    // permuted boundary table: whole-transform blocks (pre == 1) or the halves of a split transform (pre = 2 + sb,
-    // with the split-permuted copy in C.Wb)
-    const bool use_b = LAST && (pre == 1u || SPLIT) && A::has_b(C);
-    if (FIRST && SPLIT) {  // top stage of the 2^(LOGB+1) transform on the fly: v = lo +/- W[1] hi
-#pragma unroll
-        for (int i = 0; i < G::E; i++) {
-            const u64 lo = lift ? lift_digit(raw[i], *lift) : raw[i], hi = lift ? lift_digit(raw_hi[i], *lift) : raw_hi[i];
-            v[i] = A::top_stage(lo, hi, pre & 1u, C);
-        }
-        TFHE_SCHED_FENCE();
-    } else if (FIRST && lift) {  // digit lift: all conversions first, then the butterflies (register pressure)
+    const bool use_b = LAST && pre == 1u && A::has_b(C);  // permuted boundary table of whole-transform blocks
+    if (FIRST && lift) {  // digit lift: all conversions first, then the butterflies (register pressure)
 #pragma unroll
         for (int i = 0; i < G::E; i++) v[i] = A::from_global_lift(raw[i], C, *lift);
         TFHE_SCHED_FENCE();
@@ -364,7 +333,7 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
         typename A::elem* vv = v + u * G::R;
 #pragma unroll
         for (int r = 0; r < G::R; r++) {
-            if (FIRST && (lift || SPLIT)) continue;
+            if (FIRST && lift) continue;
             // 5-stage first passes sweep the range after their third stage, so residues may enter uncentred (|v| < p:
             // 1 -> 1.92 -> 3.23 -> 5.10 p, fp64arith.h); 4-stage passes have no sweep and need |v| <= p/2
             vv[r] = FIRST ? (K >= 5 ? A::from_global_plain(raw[u * G::R + r], C) : A::from_global(raw[u * G::R + r], C))
@@ -459,9 +428,7 @@ TFHE_HD void inv_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, i
             }
         }
     }
-#ifndef TFHE_NO_LOADFENCE
     TFHE_SCHED_FENCE();
-#endif
 }
 // Range plan of an inverse pass (fp64 policy): sums double per Gentleman-Sande stage while products come back to
 // <= 1/2 + 1.5 a b, so only the elements on long runs of sums ever approach the exactness limit.  Instead of sweeping

@@ -24,27 +24,9 @@ inline void permute_boundary(const std::vector<T>& in, std::vector<T>& out, int 
     }
 }
 
-// split variant: the transform is 2^x sub-blocks of 2^(logN-x); within stage s >= x + hb0 (hb0 = logN - x - Kb group bits),
-// position (2^s + (sb << (s - x)) + (c0 << d) + g) holds entry (2^s + (sb << (s - x)) + (brv_hb0(c0) << d) + g)
-template <class T>
-inline void permute_boundary_split(const std::vector<T>& in, std::vector<T>& out, int logN, int x, int Kb) {
-    out = in;
-    const int hb = logN - x - Kb;
-    for (int d = 0; d < Kb; d++) {
-        const int s = x + hb + d;
-        for (u32 sb = 0; sb < (1u << x); sb++)
-            for (u32 c0 = 0; c0 < (1u << hb); c0++) {
-                u32 r = 0;
-                for (int b = 0; b < hb; b++) r |= ((c0 >> b) & 1u) << (hb - 1 - b);
-                const size_t base = ((size_t)1 << s) + ((size_t)sb << (s - x));
-                for (u32 g = 0; g < (1u << d); g++) out[base + ((size_t)c0 << d) + g] = in[base + ((size_t)r << d) + g];
-            }
-    }
-}
-
 struct ntt_host_tabs_t {  // every table of one limb (host copies)
-    std::vector<twd_t> W, Wi, Wb, Wib, Wbs;
-    std::vector<ftwd_t> Wd, Wid, Wdb, Widb, Wdbs;
+    std::vector<twd_t> W, Wi, Wb, Wib;
+    std::vector<ftwd_t> Wd, Wid, Wdb, Widb;
 };
 
 inline int build_ntt_tables(int64_t N, u64 q, u64 psi, std::vector<twd_t>& W, std::vector<twd_t>& Wi, ntt_limb_t* L,
@@ -84,7 +66,6 @@ inline int build_ntt_tables(int64_t N, u64 q, u64 psi, std::vector<twd_t>& W, st
     L->Wd = nullptr;
     L->Winvd = nullptr;
     L->Wb = nullptr; L->Winvb = nullptr; L->Wdb = nullptr; L->Winvdb = nullptr;
-    L->Wbs = nullptr; L->Wdbs = nullptr;
     if (q < TFHE_FP_QMAX && Wd && Wid) {
         Wd->resize((size_t)N);
         Wid->resize((size_t)N);
@@ -121,11 +102,6 @@ inline int build_ntt_tables_all(int64_t N, u64 q, u64 psi, ntt_host_tabs_t& T, n
                 L->Wdb = T.Wdb.data(); L->Winvdb = T.Widb.data();
             }
         }
-    }
-    if (logN == 14) {  // split kernels: two 2^13 halves, 32 elements per thread, passes 5/5/3
-        permute_boundary_split(T.W, T.Wbs, 14, 1, 3);
-        L->Wbs = T.Wbs.data();
-        if (L->Wd) { permute_boundary_split(T.Wd, T.Wdbs, 14, 1, 3); L->Wdbs = T.Wdbs.data(); }
     }
     return 0;
 }
