@@ -106,6 +106,22 @@ def test_nntt_large_n(logn):
     assert np.array_equal(run_ntt(ctx, want, inverse=True), a)
 
 
+def test_nntt_2_15_many_rows_single_kernel():
+    """N = 2^15 with more rows than compute units: the one-kernel path (top stage in registers, both 2^14 sub-blocks per
+    workgroup) walks several rows per workgroup; variant 2 (u64 blocks + separate top-stage kernel) must agree."""
+    N, rows = 1 << 15, 2 * 256 + 7
+    qs = H.chain(50, 2, N)
+    rng = np.random.default_rng(15)
+    a = H.rand_residues(rng, qs[:1], (rows,), N)
+    a[0, 0, :4] = [0, 1, qs[0] - 1, qs[0] // 2]
+    want = ref_cpu.RefCtx(N, qs[:1]).nntt(a)
+    ctx = tf.Context(N, qs)
+    for variant in (0, 2):
+        ctx.set_ntt_variant(variant)
+        assert np.array_equal(run_ntt(ctx, a, idx=[0]), want), variant
+        assert np.array_equal(run_ntt(ctx, want, inverse=True, idx=[0]), a), variant
+
+
 def test_nntt_limb_selection_and_explicit_psi():
     N = 2048
     q, psi = 1152921504606830593, 811032584449645127    # cryptparams.jl:25
