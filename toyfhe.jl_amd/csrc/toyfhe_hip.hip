@@ -630,7 +630,7 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
     const size_t N = (size_t)c->N;
     // chunk the batch so that the digit tensor stays at a few hundred MiB
     const size_t per_ct = ((size_t)2 * nw + (size_t)level * nw + (rotate ? (size_t)polys * level : 0)) * N * 8;
-    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)128, (int64_t)((2048ull << 20) / per_ct)}));
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)((8192ull << 20) / per_ct)}));
     void* ws = nullptr;
     // NTT of N > 2^14 uses the context workspace as well: keep ours separate by over-allocating
     const size_t ntt_tmp = c->logN > 14 ? (size_t)chunk * std::max(2, level) * nw * N * 8 : 0;
@@ -723,7 +723,7 @@ int tfhe_keyswitch_window(tfhe_ctx* c, int level, int window_bits, const uint64_
     const size_t N = (size_t)c->N;
     const u32 n = (u32)c->N;
     const size_t per_ct = ((size_t)2 * level + (size_t)n_windows * level) * N * 8;
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)128, (int64_t)((2048ull << 20) / per_ct)}));
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)((8192ull << 20) / per_ct)}));
     const size_t ntt_tmp = c->logN > 14 ? (size_t)chunk * n_windows * level * N * 8 : 0;
     void* ws = nullptr;
     rc = ensure_ws(c, ntt_tmp + chunk * per_ct, &ws);
