@@ -9,6 +9,21 @@
 
 typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
 
+// Minimum waves per SIMD the row kernels are compiled for (2 = the two waves per SIMD a 512-thread workgroup occupies).
+// With 3 (a 168-VGPR cap) a streaming kernel of another chunk can be co-resident; measured (tools/two_lane_probe.py) that
+// buys +5 % from overlap but costs more in the transforms, so the default stays 2.
+#ifndef TFHE_NTT_WAVES
+#define TFHE_NTT_WAVES 2
+#endif
+
+// The thread index as an opaque per-row value: stops loop-invariant code motion from parking 30-60 VGPRs of precomputed
+// per-element addresses (global and LDS) across the whole row loop; they are re-derived with one add each instead.
+__device__ __forceinline__ u32 fresh_tid() {
+    u32 t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 struct limb_sel_t {  // which context modulus each buffer limb uses (crtselect, src/crt.jl:185-211)
     int n;
     int idx[TFHE_MAX_LIMBS];
@@ -75,7 +90,7 @@ __device__ __forceinline__ void inv_schedule(u64* lds, const u64* gsrc, u64* gds
 // Workgroups loop over items i = blockIdx.x, blockIdx.x + gridDim.x, ... (item = (row << x) + sb, row = poly*limbs + j
 // in the plain mode; see ntt_io_t for the grouped / digit-lift / addend row maps).
 template <class A, int LOGB, int LOGT, int IOMODE>
-__global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_block(const u64* __restrict__ src, u64* __restrict__ dst,
+__global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_block(const u64* __restrict__ src, u64* __restrict__ dst,
                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
                                                               u32 nitems, ntt_io_t io) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
@@ -96,7 +111,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_block(const u64* __restri
         }
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         if (item != blockIdx.x) __syncthreads();  // the previous item's last pass has read LDS
-        fwd_schedule<A, LOGB, LOGT, 0>(lds, src + srow * ntot + ((size_t)sb << LOGB), dst + drow * ntot, C, threadIdx.x,
+        fwd_schedule<A, LOGB, LOGT, 0>(lds, src + srow * ntot + ((size_t)sb << LOGB), dst + drow * ntot, C, fresh_tid(),
                                        (1u << x) + sb, x, brev_bits(sb, x), lift);
     }
 }
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_block(const u64* __restri
 // digit i); the residues of limb i of c[end] stay in registers while the workgroup lifts them into each of the nw working
 // limbs j in turn and transforms (rows (b*level + i)*nw + j of dst).  Whole-transform blocks only (x == 0).
 template <class A, int LOGB, int LOGT>
-__global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_lift(const u64* __restrict__ src, u64* __restrict__ dst,
+__global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_lift(const u64* __restrict__ src, u64* __restrict__ dst,
                                                              const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems,
                                                              ntt_io_t io) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
@@ -121,6 +136,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_lift(const u64* __restric
         lf.qi = LT[sel.idx[i]].q;
         lf.half = lf.qi >> 1;
         for (u32 j = 0; j < io.nw; j++) {
+            const u32 tid = fresh_tid();
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qj = Lj.q;
             lf.bj = Lj.br;
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restri
         if (item != blockIdx.x) __syncthreads();
         if (A::prefetch_tw && x == 0) {  // fp64 policy, whole transform: 8-byte twiddles prefetched a pass ahead
             if constexpr (A::prefetch_tw)
-                inv_schedule_ptw<A, LOGB, LOGT, LOGB>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, addend, nullptr);
+                inv_schedule_ptw<A, LOGB, LOGT, LOGB>(lds, src + srow * ntot, dst + drow * ntot, C, fresh_tid(), 1u, addend, nullptr);
         } else {
             if (x == 0)
                 inv_schedule<A, LOGB, LOGT, LOGB, true>(lds, src + srow * ntot, dst + drow * ntot, C, threadIdx.x, 1u, 0, 0u, addend);
@@ -265,7 +281,7 @@ __device__ __forceinline__ item_rows_t item_rows(u32 pl, const limb_sel_t& sel, 
 }
 
 template <class A, int LOGB, int LOGT, int IOMODE>
-__global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_staged(const u64* __restrict__ src, u64* __restrict__ dst,
+__global__ __launch_bounds__(1 << LOGT, IOMODE == 2 ? 2 : TFHE_NTT_WAVES) void k_ntt_inv_staged(const u64* __restrict__ src, u64* __restrict__ dst,
                                                                const ntt_limb_t* __restrict__ LT, limb_sel_t sel,
                                                                u32 nitems, ntt_io_t io) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
@@ -283,6 +299,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_staged(const u64* __restr
     u32 itc = 0;
     (void)itc;
     for (;;) {
+        const u32 tid = fresh_tid();
         const typename A::ctx C = A::make(LT[sel.idx[R.j]]);
         u64* gdst = dst + ((size_t)R.drow << LOGB);
         __syncthreads();
