@@ -115,6 +115,87 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_block(con
                                        (1u << x) + sb, x, brev_bits(sb, x), lift);
     }
 }
+template <class T>
+__device__ __forceinline__ void pin_vgpr(T& x) { asm volatile("" : "+v"(x)); }
+#define TFHE_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// Register-prefetch variant of the forward block kernel (whole rows, plain I/O): the operands of item i+1 are loaded
+// into registers underneath the MIDDLE pass of item i, one load per few butterflies during its first half
+// (row_prefetcher as the progress hook), so that the first pass of item i+1 starts without waiting on HBM.
+// vmcnt is one in-order counter shared by loads and stores, hence the ordering rules:
+//   * the middle pass's own twiddles are requested a pass ahead and have landed before the prefetch starts;
+//   * the last pass's twiddle loads queue behind the prefetch (it has landed by then);
+//   * everything is awaited BEFORE the stores of item i are issued -- a later wait would include their drain.
+template <int LOGB, int LOGT>
+struct row_prefetcher {
+    static constexpr int E = 1 << (LOGB - LOGT);
+    u64* raw;
+    const u64* g;  // next row + tid
+    bool on;
+    __device__ __forceinline__ void operator()(int before, int after, int total) const {
+        const int lo2 = 2 * E * before / total, hi2 = 2 * E * after / total;  // all requests in the first half of the pass
+        const int lo = lo2 < E ? lo2 : E, hi = hi2 < E ? hi2 : E;
+        if (hi > lo && on) {
+#pragma unroll
+            for (int i = lo; i < hi; i++) raw[i] = g[(size_t)i << LOGT];
+        }
+    }
+};
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_pf(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                           const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
+    static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass schedule expected");
+    typedef pgeom<LOGB, LOGT, K1, K2> G2;
+    typedef pgeom<LOGB, LOGT, K1 + K2, K3> G3;
+    static_assert(G2::SETS == 1, "middle pass: one register set");
+    constexpr int E = G3::E;
+    u32 item = blockIdx.x;
+    if (item >= nitems) return;
+    u64 raw[E];
+    fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, src + ((size_t)item << LOGB), threadIdx.x);
+    for (bool first = true;; first = false) {
+        const u32 tid = fresh_tid();
+        const typename A::ctx C = A::make(LT[sel.idx[item % (u32)sel.n]]);
+        u64* gdst = dst + ((size_t)item << LOGB);
+        const u32 next = item + gridDim.x;
+        if (!first) __syncthreads();  // the previous item's last pass has read LDS
+        typename A::tw tw2[G2::SETS * G2::NTW];
+        {
+            typename A::elem v[E];
+            fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u);
+            fwd_load_tw<A, LOGB, LOGT, K1, K2, false>(tw2, C, tid, 1u);  // arrive underneath the exchange
+            fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+        }
+        __syncthreads();
+        {
+            u64 r2[E];
+            typename A::elem v[E];
+            fwd_load_data<LOGB, LOGT, K1, K2, false, false>(r2, lds, nullptr, tid);
+#pragma unroll
+            for (int i = 0; i < G2::SETS * G2::NTW; i++) pin_vgpr(tw2[i].w);  // landed before the prefetch starts
+            const row_prefetcher<LOGB, LOGT> pf{raw, src + ((size_t)(next < nitems ? next : item) << LOGB) + tid, next < nitems};
+            fwd_compute<A, LOGB, LOGT, K1, K2, false, false, K2, -1, row_prefetcher<LOGB, LOGT>>(v, r2, tw2, C, tid, 1u, nullptr, pf);
+            fwd_store<A, LOGB, LOGT, K1, K2, false>(v, lds, nullptr, C, tid, 0, 0u);
+        }
+        __syncthreads();
+        {
+            u64 r3[E];
+            typename A::elem v[E];
+            fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
+            fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, 1u);
+            TFHE_SCHED_FENCE();
+            TFHE_WAIT_VM0();  // the prefetched row is in registers; nothing older than the stores below is pending
+#pragma unroll
+            for (int i = 0; i < E; i++) pin_vgpr(raw[i]);
+            fwd_store<A, LOGB, LOGT, K1 + K2, K3, true>(v, lds, gdst, C, tid, 0, 0u);
+        }
+        if (next >= nitems) break;
+        item = next;
+    }
+}
+
+
 // Digit-lift forward transforms of the key switch (ntt_io_t mode 1) with the source row read ONCE: item = (ciphertext b,
 // digit i); the residues of limb i of c[end] stay in registers while the workgroup lifts them into each of the nw working
 // limbs j in turn and transforms (rows (b*level + i)*nw + j of dst).  Whole-transform blocks only (x == 0).
@@ -199,7 +280,6 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restri
 // vmcnt is one in-order counter for loads, so every ordinary vector load whose result is needed while the
 // DMA is in flight (last-pass twiddles, addends) is issued and waited for BEFORE the DMA is started.
 // ------------------------------------------------------------------------------------------------
-#define TFHE_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #ifdef TFHE_TRACE  // design aid (tools/ntt_ablate.hip): shader-clock stamps of one workgroup's phases
 __device__ unsigned long long tfhe_trace[64 * 16];
 #define TFHE_STAMP(k)                                                                                   \
@@ -250,8 +330,6 @@ struct row_stager {
         }
     }
 };
-template <class T>
-__device__ __forceinline__ void pin_vgpr(T& x) { asm volatile("" : "+v"(x)); }
 
 struct item_rows_t {
     u32 srow, drow, j;
@@ -299,7 +377,7 @@ __global__ __launch_bounds__(1 << LOGT, IOMODE == 2 ? 2 : TFHE_NTT_WAVES) void k
     u32 itc = 0;
     (void)itc;
     for (;;) {
-        const u32 tid = fresh_tid();
+        const u32 tid = IOMODE == 2 ? threadIdx.x : fresh_tid();  // (the addend variant measured faster with hoisted addresses)
         const typename A::ctx C = A::make(LT[sel.idx[R.j]]);
         u64* gdst = dst + ((size_t)R.drow << LOGB);
         __syncthreads();

@@ -155,6 +155,19 @@ int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const 
             return TFHE_OK;
         }
     }
+    if constexpr (std::is_same<A, ArithFp>::value && LOGB == 14 && IOMODE == 0) {
+        if (x == 0 && c->variant == 0) {  // next row prefetched into registers under the middle pass: +6 % stand-alone, neutral inside the BFV pipeline
+            auto pkern = k_ntt_fwd_pf<A, LOGB, LOGT>;
+            static bool pattr_set = false;
+            if (!pattr_set) { int rc = set_lds(pkern, lds); if (rc) return rc; pattr_set = true; }
+            const unsigned pgrid = std::min((unsigned)rows, (unsigned)c->num_cus);
+            prof_begin(c, rows);
+            hipLaunchKernelGGL(pkern, dim3(pgrid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows);
+            prof_end(c);
+            HIP_TRY(hipGetLastError());
+            return TFHE_OK;
+        }
+    }
     auto kern = k_ntt_fwd_block<A, LOGB, LOGT, IOMODE>;
     static bool attr_set = false;
     if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
