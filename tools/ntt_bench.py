@@ -8,7 +8,7 @@ from tests import helpers as H
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-N, L = 1 << 14, 8
+N, L = 1 << 14, int(os.environ.get("NTT_L", "8"))
 ctx = tf.Context(N, H.chain(50, L, N))
 a, b = tf.DeviceBuffer(rows * N), tf.DeviceBuffer(rows * N)
 tf.native.check(tf.native.lib().tfhe_memset(ctx.h, a.ptr, 1, rows * N * 8))
