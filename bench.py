@@ -3,7 +3,8 @@
 limbs, batch = 1024 per GPU (configs[1]); NTT GB/s against the HBM roofline from the same timed region.
 
 A "step" is one pass of the hot path (tfhe_bfv_mul_relin: exact expand 8->17 limbs, 68 forward limb-NTTs,
-tensor, 51 inverse limb-NTTs, exact scale-and-round back to 8 limbs, RNS-digit key switch) over one batch
+tensor, 51 inverse limb-NTTs, exact scale-and-round back to 8 limbs, RNS-digit key switch: 64 + 16 more transforms
+inside one fused kernel) over one batch
 of synthetic ciphertexts already resident in HBM.  One process per GPU; ranks shard the batch (weak
 scaling: the per-GPU batch is fixed), no data-path collective.
 
@@ -97,12 +98,13 @@ def main():
     achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
     # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs, gfx950 corrections;
     # tools/pmc_probe.py + tools/pmc_summarize.py).  bench.py cannot run the counters itself, so it applies the committed
-    # per-limb-NTT figures to this run's launch sizes: 132 forward and 67 inverse limb transforms per ciphertext-mul.
+    # per-limb-NTT figures to this run's launch sizes: 68 forward and 51 inverse limb transforms per ciphertext-mul in the
+    # stand-alone NTT kernels (the 64 + 16 of the key switch live inside k_ks_fused).
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_ntt_traffic.json")
     if os.path.exists(pmc_path) and launches:
         pmc = json.load(open(pmc_path))
-        per_ntt = (132 * pmc["fwd"]["hbm_bytes_per_limb_ntt"] + 67 * pmc["inv"]["hbm_bytes_per_limb_ntt"]) / 199.0
+        per_ntt = (68 * pmc["fwd"]["hbm_bytes_per_limb_ntt"] + 51 * pmc["inv"]["hbm_bytes_per_limb_ntt"]) / 119.0
         traffic = per_ntt * limb_polys / launches
     result = {
         "metric": "ciphertext-mul/s (BFV ct*ct + relinearize, N=2^14, L=8 RNS)",
@@ -120,8 +122,8 @@ def main():
         "config": {"workload": "BFV N=2^14, L=8 RNS limbs (50-bit primes), extension basis 17 limbs, t=65537, "
                                "ciphertext-mul + relinearize (RNS-digit keyswitch), bit-exact", "batch_per_gpu": B,
                    "global_batch": B * world, "sharding": f"batch x{world}, no data-path collective"},
-        "roofline": {"bound": "hbm", "kernel": "2^14-point negacyclic NTT kernels (k_ntt_fwd_block / k_ntt_fwd_lift / k_ntt_inv_staged, "
-                               "fp64 butterflies, one limb row per workgroup pass)",
+        "roofline": {"bound": "hbm", "kernel": "2^14-point negacyclic NTT kernels (k_ntt_fwd_pf / k_ntt_inv_staged, fp64 butterflies, one limb "
+                               "row per workgroup pass); the key switch's own transforms run inside k_ks_fused and are not counted",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_unit": "bytes per launch (PMC bytes per limb-NTT from profiles/r01_pmc_ntt_traffic.json "
                                                          "x limb-NTTs per launch)",

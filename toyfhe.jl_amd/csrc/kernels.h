@@ -878,6 +878,100 @@ __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Whole RNS-digit key switch (no special prime) for one (ciphertext b, limb j) per workgroup pass, fp64 policy,
+// whole-transform blocks:   out_s[b][j] = c_s[b][j] + INTT_j( Σ_i evk_{i,s}[j] ⊙ NTT_j(lift_{i→j}(c_end[b][i])) )
+// The digit transforms never leave the CU: after the last forward pass each thread holds 2^(LOGB-LOGT) transform values
+// in registers, multiplies them by the two key components (streamed from L2; the key is shared by the whole batch) and
+// accumulates; the two accumulators then go straight into the inverse transform, whose first pass uses the same
+// natural-order register map.  HBM traffic per ciphertext: `level` source rows + (polys-1)*level addend rows read and
+// 2*level rows written, instead of writing and re-reading level*level digit rows and 2*level accumulator rows.
+// ------------------------------------------------------------------------------------------------
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ evk, const u64* __restrict__ ct,
+                                                         u64* __restrict__ out, const ntt_limb_t* __restrict__ LT,
+                                                         ks_arg_t KA, int Lk, u32 nitems) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
+    static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass forward schedule expected");
+    constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB);
+    static_assert(KI1 == K3, "forward last pass and inverse first pass must share the register map");
+    typedef pgeom<LOGB, LOGT, 0, K1> G1;
+    typedef pgeom<LOGB, LOGT, K1 + K2, K3> G3;
+    constexpr int E = G3::E;
+    const u32 level = (u32)KA.level, polys = (u32)KA.polys;
+    const u32 add_s = polys == 3 ? 2u : 1u;
+    bool first = true;
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const u32 b = item / level, j = item % level;
+        const ntt_limb_t& Lj = LT[KA.w.idx[j]];
+        const typename A::ctx C = A::make(Lj);
+        lift_t lf;
+        lf.qj = Lj.q;
+        lf.bj = Lj.br;
+        typename A::elem acc[2][E];
+#pragma unroll
+        for (int e = 0; e < E; e++) acc[0][e] = acc[1][e] = 0;
+        for (u32 i = 0; i < level; i++) {
+            const u32 tid = fresh_tid();
+            lf.qi = LT[KA.w.idx[i]].q;
+            lf.half = lf.qi >> 1;
+            const u64* grow = ct + ((size_t)((b * polys + polys - 1) * level + i) << LOGB);
+            typename A::elem v[E];
+            {
+                u64 raw[E];
+                fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, grow, tid);
+                if (!first) __syncthreads();  // the previous transform's last pass has read LDS
+                first = false;
+                fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u, &lf);
+                fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+            }
+            __syncthreads();
+            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
+            __syncthreads();
+            {
+                u64 r3[E];
+                fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
+                fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, 1u);
+            }
+            // multiply-accumulate with the key: component 1 (masked) feeds out_0, component 0 (mask) feeds out_1
+            const u64* e_mask = evk + (((size_t)i * 2 + 0) * Lk + KA.w.idx[j] << LOGB);
+            const u64* e_masked = evk + (((size_t)i * 2 + 1) * Lk + KA.w.idx[j] << LOGB);
+#pragma unroll
+            for (int u = 0; u < G3::SETS; u++) {
+                u32 c0, hi, base;
+                G3::template coords<true>(tid, u, c0, hi, base);
+#pragma unroll
+                for (int r = 0; r < G3::R; r++) {
+                    const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
+                    const int e = u * G3::R + r;
+                    const typename A::tw k1{fp_from_u64(e_masked[nat])}, k0{fp_from_u64(e_mask[nat])};
+                    acc[0][e] += fp_mulmod_c(v[e], k1, C.p, C.pinv);
+                    acc[1][e] += fp_mulmod_c(v[e], k0, C.p, C.pinv);
+                }
+            }
+        }
+        // inverse transforms of the two accumulators; the first pass takes them from registers (same natural-order map)
+#pragma unroll
+        for (int sidx = 0; sidx < 2; sidx++) {
+            const u32 tid = fresh_tid();
+            u64 raw[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) raw[e] = fp_canon(acc[sidx][e], C.p, C.pinv);
+            const u64* addend = (u32)sidx < add_s ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : nullptr;
+            u64* gdst = out + ((size_t)((b * 2 + sidx) * level + j) << LOGB);
+            __syncthreads();  // the previous transform's last pass has read LDS
+            {
+                typename A::elem v[E];
+                inv_compute<A, LOGB, LOGT, LOGB - KI1, KI1, true, true, 0>(v, raw, nullptr, C, tid, 1u);
+                inv_store<A, LOGB, LOGT, LOGB - KI1, KI1, true, true>(v, lds, nullptr, C, tid);
+            }
+            __syncthreads();
+            inv_schedule<A, LOGB, LOGT, LOGB - KI1, true>(lds, nullptr, gdst, C, tid, 1u, 0, 0u, addend);
+        }
+    }
+}
+
 // RNS digits as a separate pass (only for N > 2^14, where the lift is not fused into the NTT loads):
 // dig [batch][level][nw][N]; digit i, limb j = centred([c_end]_{q_i}) mod q_w[j]  (rlwe_she.jl:326-329)
 __global__ __launch_bounds__(256) void k_ks_digits(const u64* __restrict__ ct, u64* __restrict__ dig,

@@ -577,6 +577,21 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
     const u32 n = (u32)c->N;
     const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
     int rc;
+    if (!special && c->logN == 14 && c->variant == 0 && sel_fp(c, A.w, 0)) {
+        // everything in one kernel: digit lift, forward transforms, key inner product and the two inverse transforms
+        constexpr int LOGT = logt_for(14);
+        const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
+        auto fk = k_ks_fused<ArithFp, 14, LOGT>;
+        static bool fattr_set = false;
+        if (!fattr_set) { rc = set_lds(fk, lds); if (rc) return rc; fattr_set = true; }
+        const unsigned items = (unsigned)(batch * level);
+        const unsigned grid = std::min(items, (unsigned)c->num_cus);
+        prof_begin(c, 0);  // not an NTT launch for the roofline accounting: transforms, key products and additions are fused
+        hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evk, ct, out, c->limbs_dev, A, Lk, items);
+        prof_end(c);
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
     if (c->logN <= 14) {
         // digits: centred lift of limb i of c[end] into every working limb, fused into the forward NTT's loads
         ntt_io_t io = io_plain();
