@@ -144,7 +144,7 @@ struct ArithInt {
     static TFHE_HD bool has_b(const ctx& c) { return c.Wb != nullptr; }
     static TFHE_HD elem from_global(u64 x, const ctx&) { return x; }
     static TFHE_HD elem from_global_plain(u64 x, const ctx&) { return x; }
-    static TFHE_HD elem from_global_lift(u64 x, const ctx&, const lift_t& f) { return lift_digit(x, f); }
+    static TFHE_HD elem from_global_lift(u64 x, const ctx&, const lift_t& f, bool = false) { return lift_digit(x, f); }
     static TFHE_HD elem from_lds(u64 x) { return x; }
     static TFHE_HD u64 to_lds(elem v) { return v; }
     static TFHE_HD tw ld_fwd(const ctx& c, u32 i) { return ld_tw(c.W, i); }
@@ -183,10 +183,12 @@ struct ArithFp {
     }
     static TFHE_HD elem from_global_plain(u64 x, const ctx&) { return fp_from_u64(x); }
     // digit lift in fp64: centred residue of limb i (|d| <= q_i/2 < 2^51, exact) reduced mod p_j
-    static TFHE_HD elem from_global_lift(u64 x, const ctx& c, const lift_t& f) {
+    // loose: the caller's first pass accepts |v| <= p (5-stage passes with their mid-pass sweep): the centred digit,
+    // |d| <= q_i / 2, needs no reduction when q_i <= 2 p (moduli of one size class)
+    static TFHE_HD elem from_global_lift(u64 x, const ctx& c, const lift_t& f, bool loose = false) {
         double d = fp_from_u64(x);
         d = x > f.half ? d - (double)f.qi : d;
-        return fp_reduce(d, c.p, c.pinv);
+        return (loose && f.qi <= 2 * c.q) ? d : fp_reduce(d, c.p, c.pinv);
     }
     static TFHE_HD elem from_lds(u64 x) { double d; __builtin_memcpy(&d, &x, 8); return d; }
     static TFHE_HD u64 to_lds(elem v) { u64 b; __builtin_memcpy(&b, &v, 8); return b; }
@@ -322,7 +324,7 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
     const bool use_b = LAST && pre == 1u && A::has_b(C);  // permuted boundary table of whole-transform blocks
     if (FIRST && lift) {  // digit lift: all conversions first, then the butterflies (register pressure)
 #pragma unroll
-        for (int i = 0; i < G::E; i++) v[i] = A::from_global_lift(raw[i], C, *lift);
+        for (int i = 0; i < G::E; i++) v[i] = A::from_global_lift(raw[i], C, *lift, K >= 5);
         TFHE_SCHED_FENCE();
     }
 #pragma unroll
