@@ -972,6 +972,122 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The inside of a BFV multiplication for one (ciphertext b, limb j of ℛbig) per workgroup pass, fp64 policy, whole-
+// transform blocks:   T_k[b][j] = INTT_j( tensor_k( NTT_j(a0), NTT_j(a1), NTT_j(b0), NTT_j(b1) ) ),  k = 0, 1, 2
+// (enc_mul, rlwe_she.jl:255-258, between mul_expand and mul_contract).  The four forward transforms, the tensor product
+// and the three inverse transforms never leave the CU: NTT(a0), NTT(a1) are held in registers (2 x 32 doubles per
+// thread) while b0 and b1 are transformed; products are formed in place and go straight into the inverse transform
+// (its first pass shares the forward last pass's natural-order register map).  One intermediate row (a1 b0) makes a
+// round trip through a per-workgroup scratch row (L2 / Infinity Cache).  HBM traffic per limb: 4 rows read + 3 written
+// (+ 2 scratch) instead of 21 row moves for forward kernel + tensor kernel + inverse kernel.
+// ------------------------------------------------------------------------------------------------
+template <class A, int LOGB, int LOGT>
+__device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, const typename A::ctx& C, bool& first,
+                                                  typename A::elem* v) {
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
+    constexpr int E = 1 << (LOGB - LOGT);
+    const u32 tid = fresh_tid();
+    {
+        u64 raw[E];
+        fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, grow, tid);
+        if (!first) __syncthreads();  // the previous transform's last pass has read LDS
+        first = false;
+        fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u);
+        fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+    }
+    __syncthreads();
+    ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
+    __syncthreads();
+    {
+        u64 r3[E];
+        fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
+        fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, 1u);
+    }
+}
+// inverse transform of canonical residues held in the forward-last-pass register map; result (+ addend) to gdst
+template <class A, int LOGB, int LOGT>
+__device__ __forceinline__ void fused_inv_from_regs(u64* lds, const u64* raw, u64* gdst, const typename A::ctx& C, const u64* addend) {
+    constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB);
+    constexpr int E = 1 << (LOGB - LOGT);
+    const u32 tid = fresh_tid();
+    __syncthreads();  // the previous transform's last pass has read LDS
+    {
+        typename A::elem v[E];
+        inv_compute<A, LOGB, LOGT, LOGB - KI1, KI1, true, true, 0>(v, raw, nullptr, C, tid, 1u);
+        inv_store<A, LOGB, LOGT, LOGB - KI1, KI1, true, true>(v, lds, nullptr, C, tid);
+    }
+    __syncthreads();
+    inv_schedule<A, LOGB, LOGT, LOGB - KI1, true>(lds, nullptr, gdst, C, tid, 1u, 0, 0u, addend);
+}
+
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restrict__ Ea, const u64* __restrict__ Eb,
+                                                               u64* __restrict__ T, u64* __restrict__ scratch,
+                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K3 = LOGB - pass_k_fwd(LOGB, LOGT, 0) - pass_k_fwd(LOGB, LOGT, pass_k_fwd(LOGB, LOGT, 0));
+    static_assert(pass_k_inv(LOGB, LOGT, LOGB) == K3, "forward last pass and inverse first pass must share the register map");
+    typedef pgeom<LOGB, LOGT, LOGB - K3, K3> G3;
+    constexpr int E = G3::E;
+    const u32 nb = (u32)sel.n;
+    u64* const srow = scratch + ((size_t)blockIdx.x << LOGB);
+    bool first = true;
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const u32 b = item / nb, j = item % nb;
+        const typename A::ctx C = A::make(LT[sel.idx[j]]);
+        const size_t r0 = ((size_t)(b * 2 + 0) * nb + j) << LOGB, r1 = ((size_t)(b * 2 + 1) * nb + j) << LOGB;
+        u64* const t0 = T + (((size_t)(b * 3 + 0) * nb + j) << LOGB);
+        u64* const t1 = T + (((size_t)(b * 3 + 1) * nb + j) << LOGB);
+        u64* const t2 = T + (((size_t)(b * 3 + 2) * nb + j) << LOGB);
+        typename A::elem A0[E], A1[E], v[E];
+        fused_fwd_to_regs<A, LOGB, LOGT>(lds, Ea + r0, C, first, A0);
+#pragma unroll
+        for (int e = 0; e < E; e++) A0[e] = fp_reduce(A0[e], C.p, C.pinv);
+        fused_fwd_to_regs<A, LOGB, LOGT>(lds, Ea + r1, C, first, A1);
+#pragma unroll
+        for (int e = 0; e < E; e++) A1[e] = fp_reduce(A1[e], C.p, C.pinv);
+        fused_fwd_to_regs<A, LOGB, LOGT>(lds, Eb + r0, C, first, v);
+        {
+            const u32 tid = fresh_tid();
+            u64 raw[E];
+#pragma unroll
+            for (int u = 0; u < G3::SETS; u++) {
+                u32 c0, hi, base;
+                G3::template coords<true>(tid, u, c0, hi, base);
+#pragma unroll
+                for (int r = 0; r < G3::R; r++) {
+                    const int e = u * G3::R + r;
+                    const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
+                    srow[nat] = fp_canon(fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv), C.p, C.pinv);   // a1 b0, parked
+                    raw[e] = fp_canon(fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv), C.p, C.pinv);     // a0 b0
+                }
+            }
+            fused_inv_from_regs<A, LOGB, LOGT>(lds, raw, t0, C, nullptr);
+        }
+        fused_fwd_to_regs<A, LOGB, LOGT>(lds, Eb + r1, C, first, v);
+        {
+            const u32 tid = fresh_tid();
+            u64 raw1[E], raw2[E];
+#pragma unroll
+            for (int u = 0; u < G3::SETS; u++) {
+                u32 c0, hi, base;
+                G3::template coords<true>(tid, u, c0, hi, base);
+#pragma unroll
+                for (int r = 0; r < G3::R; r++) {
+                    const int e = u * G3::R + r;
+                    const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
+                    const double p01 = fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv) + fp_from_u64(srow[nat]);   // a0 b1 + a1 b0
+                    raw1[e] = fp_canon(p01, C.p, C.pinv);
+                    raw2[e] = fp_canon(fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv), C.p, C.pinv);               // a1 b1
+                }
+            }
+            fused_inv_from_regs<A, LOGB, LOGT>(lds, raw1, t1, C, nullptr);
+            fused_inv_from_regs<A, LOGB, LOGT>(lds, raw2, t2, C, nullptr);
+        }
+    }
+}
+
 // RNS digits as a separate pass (only for N > 2^14, where the lift is not fused into the NTT loads):
 // dig [batch][level][nw][N]; digit i, limb j = centred([c_end]_{q_i}) mod q_w[j]  (rlwe_she.jl:326-329)
 __global__ __launch_bounds__(256) void k_ks_digits(const u64* __restrict__ ct, u64* __restrict__ dig,

@@ -309,6 +309,26 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
     return TFHE_OK;
 }
 
+// forward transforms + tensor + inverse transforms of one BFV multiplication chunk in one kernel (fp64 policy, N = 2^14);
+// *done = false when the configuration is not covered.  scratch: one row per workgroup.
+int launch_bfv_core_fused(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64* scratch, int64_t nct, const limb_sel_t& sel, bool* done) {
+    *done = false;
+    if (c->variant != 0 || c->logN != 14 || !sel_fp(c, sel, 0) || nct * sel.n > 0x7fffffffll) return TFHE_OK;
+    constexpr int LOGT = logt_for(14);
+    const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
+    auto kern = k_bfv_core_fused<ArithFp, 14, LOGT>;
+    static bool attr_set = false;
+    if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
+    const unsigned items = (unsigned)(nct * sel.n);
+    const unsigned grid = std::min(items, (unsigned)c->num_cus);
+    prof_begin(c, 0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, Ea, Eb, T, scratch, c->limbs_dev, sel, items);
+    prof_end(c);
+    HIP_TRY(hipGetLastError());
+    *done = true;
+    return TFHE_OK;
+}
+
 template <int OP>
 int run_pointwise(tfhe_ctx* c, const u64* a, const u64* b, const u64* acc, u64* dst, int64_t count, int limbs,
                   const int32_t* idx, const scal_arg_t* sc) {
