@@ -878,6 +878,51 @@ __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk
     }
 }
 
+// ---- shared pieces of the fused kernels: a forward transform that ends in registers (last pass's natural-order map)
+// and an inverse transform that starts from registers in that same map ----
+template <class A, int LOGB, int LOGT>
+__device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, const typename A::ctx& C, bool& first,
+                                                  typename A::elem* v, const lift_t* lift = nullptr) {
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
+    constexpr int E = 1 << (LOGB - LOGT);
+    const u32 tid = fresh_tid();
+    {
+        u64 raw[E];
+        fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, grow, tid);
+        if (!first) __syncthreads();  // the previous transform's last pass has read LDS
+        first = false;
+        fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u, lift);
+        fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+    }
+    __syncthreads();
+    ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
+    __syncthreads();
+    {
+        u64 r3[E];
+        fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
+        fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, 1u);
+    }
+}
+// inverse transform of canonical residues held in the forward-last-pass register map; result (+ addend) to gdst
+template <class A, int LOGB, int LOGT>
+__device__ __forceinline__ void fused_inv_from_regs(u64* lds, const u64* raw, u64* gdst, const typename A::ctx& C, const u64* addend) {
+    constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB);
+    constexpr int E = 1 << (LOGB - LOGT);
+    const u32 tid = fresh_tid();
+    __syncthreads();  // the previous transform's last pass has read LDS
+    constexpr int S1 = LOGB - KI1, K2 = pass_k_inv(LOGB, LOGT, S1);
+    typedef pgeom<LOGB, LOGT, S1 - K2, K2> G2;
+    typename A::tw tw_next[G2::SETS * G2::NTW];  // middle-pass twiddles, requested before the exchange
+    {
+        typename A::elem v[E];
+        inv_compute<A, LOGB, LOGT, S1, KI1, true, true, 0>(v, raw, nullptr, C, tid, 1u);
+        if constexpr (S1 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S1 - K2, K2, false>(tw_next, C, tid, 1u);
+        inv_store<A, LOGB, LOGT, S1, KI1, true, true>(v, lds, nullptr, C, tid);
+    }
+    __syncthreads();
+    inv_schedule_ptw<A, LOGB, LOGT, S1>(lds, nullptr, gdst, C, tid, 1u, addend, tw_next);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Whole RNS-digit key switch (no special prime) for one (ciphertext b, limb j) per workgroup pass, fp64 policy,
 // whole-transform blocks:   out_s[b][j] = c_s[b][j] + INTT_j( Σ_i evk_{i,s}[j] ⊙ NTT_j(lift_{i→j}(c_end[b][i])) )
@@ -918,22 +963,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
             lf.half = lf.qi >> 1;
             const u64* grow = ct + ((size_t)((b * polys + polys - 1) * level + i) << LOGB);
             typename A::elem v[E];
-            {
-                u64 raw[E];
-                fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, grow, tid);
-                if (!first) __syncthreads();  // the previous transform's last pass has read LDS
-                first = false;
-                fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u, &lf);
-                fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
-            }
-            __syncthreads();
-            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
-            __syncthreads();
-            {
-                u64 r3[E];
-                fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
-                fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, 1u);
-            }
+            fused_fwd_to_regs<A, LOGB, LOGT>(lds, grow, C, first, v, &lf);
             // multiply-accumulate with the key: component 1 (masked) feeds out_0, component 0 (mask) feeds out_1
             const u64* e_mask = evk + (((size_t)i * 2 + 0) * Lk + KA.w.idx[j] << LOGB);
             const u64* e_masked = evk + (((size_t)i * 2 + 1) * Lk + KA.w.idx[j] << LOGB);
@@ -960,14 +990,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
             for (int e = 0; e < E; e++) raw[e] = fp_canon(acc[sidx][e], C.p, C.pinv);
             const u64* addend = (u32)sidx < add_s ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : nullptr;
             u64* gdst = out + ((size_t)((b * 2 + sidx) * level + j) << LOGB);
-            __syncthreads();  // the previous transform's last pass has read LDS
-            {
-                typename A::elem v[E];
-                inv_compute<A, LOGB, LOGT, LOGB - KI1, KI1, true, true, 0>(v, raw, nullptr, C, tid, 1u);
-                inv_store<A, LOGB, LOGT, LOGB - KI1, KI1, true, true>(v, lds, nullptr, C, tid);
-            }
-            __syncthreads();
-            inv_schedule<A, LOGB, LOGT, LOGB - KI1, true>(lds, nullptr, gdst, C, tid, 1u, 0, 0u, addend);
+            fused_inv_from_regs<A, LOGB, LOGT>(lds, raw, gdst, C, addend);
         }
     }
 }
@@ -982,45 +1005,6 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 // round trip through a per-workgroup scratch row (L2 / Infinity Cache).  HBM traffic per limb: 4 rows read + 3 written
 // (+ 2 scratch) instead of 21 row moves for forward kernel + tensor kernel + inverse kernel.
 // ------------------------------------------------------------------------------------------------
-template <class A, int LOGB, int LOGT>
-__device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, const typename A::ctx& C, bool& first,
-                                                  typename A::elem* v) {
-    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
-    constexpr int E = 1 << (LOGB - LOGT);
-    const u32 tid = fresh_tid();
-    {
-        u64 raw[E];
-        fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, grow, tid);
-        if (!first) __syncthreads();  // the previous transform's last pass has read LDS
-        first = false;
-        fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u);
-        fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
-    }
-    __syncthreads();
-    ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
-    __syncthreads();
-    {
-        u64 r3[E];
-        fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
-        fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, 1u);
-    }
-}
-// inverse transform of canonical residues held in the forward-last-pass register map; result (+ addend) to gdst
-template <class A, int LOGB, int LOGT>
-__device__ __forceinline__ void fused_inv_from_regs(u64* lds, const u64* raw, u64* gdst, const typename A::ctx& C, const u64* addend) {
-    constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB);
-    constexpr int E = 1 << (LOGB - LOGT);
-    const u32 tid = fresh_tid();
-    __syncthreads();  // the previous transform's last pass has read LDS
-    {
-        typename A::elem v[E];
-        inv_compute<A, LOGB, LOGT, LOGB - KI1, KI1, true, true, 0>(v, raw, nullptr, C, tid, 1u);
-        inv_store<A, LOGB, LOGT, LOGB - KI1, KI1, true, true>(v, lds, nullptr, C, tid);
-    }
-    __syncthreads();
-    inv_schedule<A, LOGB, LOGT, LOGB - KI1, true>(lds, nullptr, gdst, C, tid, 1u, 0, 0u, addend);
-}
-
 template <class A, int LOGB, int LOGT>
 __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restrict__ Ea, const u64* __restrict__ Eb,
                                                                u64* __restrict__ T, u64* __restrict__ scratch,
@@ -1050,7 +1034,6 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
         fused_fwd_to_regs<A, LOGB, LOGT>(lds, Eb + r0, C, first, v);
         {
             const u32 tid = fresh_tid();
-            u64 raw[E];
 #pragma unroll
             for (int u = 0; u < G3::SETS; u++) {
                 u32 c0, hi, base;
@@ -1060,30 +1043,41 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
                     const int e = u * G3::R + r;
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
                     srow[nat] = fp_canon(fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv), C.p, C.pinv);   // a1 b0, parked
-                    raw[e] = fp_canon(fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv), C.p, C.pinv);     // a0 b0
+                    v[e] = fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv);                                // a0 b0, in place
                 }
             }
+            u64 raw[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) raw[e] = fp_canon(v[e], C.p, C.pinv);
             fused_inv_from_regs<A, LOGB, LOGT>(lds, raw, t0, C, nullptr);
         }
         fused_fwd_to_regs<A, LOGB, LOGT>(lds, Eb + r1, C, first, v);
         {
             const u32 tid = fresh_tid();
-            u64 raw1[E], raw2[E];
 #pragma unroll
-            for (int u = 0; u < G3::SETS; u++) {
+            for (int u = 0; u < G3::SETS; u++) {  // products in place: A0 <- a0 b1 + a1 b0, A1 <- a1 b1
                 u32 c0, hi, base;
                 G3::template coords<true>(tid, u, c0, hi, base);
 #pragma unroll
                 for (int r = 0; r < G3::R; r++) {
                     const int e = u * G3::R + r;
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
-                    const double p01 = fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv) + fp_from_u64(srow[nat]);   // a0 b1 + a1 b0
-                    raw1[e] = fp_canon(p01, C.p, C.pinv);
-                    raw2[e] = fp_canon(fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv), C.p, C.pinv);               // a1 b1
+                    A0[e] = fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv) + fp_from_u64(srow[nat]);
+                    A1[e] = fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv);
                 }
             }
-            fused_inv_from_regs<A, LOGB, LOGT>(lds, raw1, t1, C, nullptr);
-            fused_inv_from_regs<A, LOGB, LOGT>(lds, raw2, t2, C, nullptr);
+            {
+                u64 raw[E];
+#pragma unroll
+                for (int e = 0; e < E; e++) raw[e] = fp_canon(A0[e], C.p, C.pinv);
+                fused_inv_from_regs<A, LOGB, LOGT>(lds, raw, t1, C, nullptr);
+            }
+            {
+                u64 raw[E];
+#pragma unroll
+                for (int e = 0; e < E; e++) raw[e] = fp_canon(A1[e], C.p, C.pinv);
+                fused_inv_from_regs<A, LOGB, LOGT>(lds, raw, t2, C, nullptr);
+            }
         }
     }
 }
