@@ -2,9 +2,9 @@
 """bench.py -- BASELINE.json metric: BFV ciphertext-mul (+ relinearise) per second at N = 2^14, L = 8 RNS
 limbs, batch = 1024 per GPU (configs[1]); NTT GB/s against the HBM roofline from the same timed region.
 
-A "step" is one pass of the hot path (tfhe_bfv_mul_relin: exact expand 8->17 limbs, 68 forward limb-NTTs,
-tensor, 51 inverse limb-NTTs, exact scale-and-round back to 8 limbs, RNS-digit key switch: 64 + 16 more transforms
-inside one fused kernel) over one batch
+A "step" is one pass of the hot path (tfhe_bfv_mul_relin: exact expand 8->17 limbs; 68 forward limb-NTTs, tensor and
+51 inverse limb-NTTs in one fused kernel; exact scale-and-round back to 8 limbs; RNS-digit key switch with its 64 + 16
+transforms in a second fused kernel) over one batch
 of synthetic ciphertexts already resident in HBM.  One process per GPU; ranks shard the batch (weak
 scaling: the per-GPU batch is fixed), no data-path collective.
 
@@ -97,15 +97,14 @@ def main():
     ntt_bytes = limb_polys * 2 * N * 8                   # one read + one write per limb transform
     achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
     # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs, gfx950 corrections;
-    # tools/pmc_probe.py + tools/pmc_summarize.py).  bench.py cannot run the counters itself, so it applies the committed
-    # per-limb-NTT figures to this run's launch sizes: 68 forward and 51 inverse limb transforms per ciphertext-mul in the
-    # stand-alone NTT kernels (the 64 + 16 of the key switch live inside k_ks_fused).
+    # tools/pmc_bench.py over this very script at batch 256).  bench.py cannot run the counters itself, so it scales the
+    # committed per-ciphertext figure of the two transform-carrying kernels to this run's launches.
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_ntt_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_bench_kernels.json")
     if os.path.exists(pmc_path) and launches:
         pmc = json.load(open(pmc_path))
-        per_ntt = (68 * pmc["fwd"]["hbm_bytes_per_limb_ntt"] + 51 * pmc["inv"]["hbm_bytes_per_limb_ntt"]) / 119.0
-        traffic = per_ntt * limb_polys / launches
+        per_ct = sum(k["hbm_bytes_per_launch"] for name, k in pmc["kernels"].items() if "fused" in name) / pmc["batch"]
+        traffic = per_ct * B * args.steps / launches
     result = {
         "metric": "ciphertext-mul/s (BFV ct*ct + relinearize, N=2^14, L=8 RNS)",
         "value": value,
@@ -122,11 +121,13 @@ def main():
         "config": {"workload": "BFV N=2^14, L=8 RNS limbs (50-bit primes), extension basis 17 limbs, t=65537, "
                                "ciphertext-mul + relinearize (RNS-digit keyswitch), bit-exact", "batch_per_gpu": B,
                    "global_batch": B * world, "sharding": f"batch x{world}, no data-path collective"},
-        "roofline": {"bound": "hbm", "kernel": "2^14-point negacyclic NTT kernels (k_ntt_fwd_pf / k_ntt_inv_staged, fp64 butterflies, one limb "
-                               "row per workgroup pass); the key switch's own transforms run inside k_ks_fused and are not counted",
+        "roofline": {"bound": "hbm", "kernel": "k_bfv_core_fused + k_ks_fused: the 2^14-point negacyclic NTTs (fp64 butterflies) fused with the "
+                               "tensor product / key inner product -- 7 and 10 limb transforms per workgroup item; units = limb "
+                               "transforms x 2*N*8 algorithmic bytes (SURVEY 8d), durations by HIP events around these launches",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_unit": "bytes per launch (PMC bytes per limb-NTT from profiles/r01_pmc_ntt_traffic.json "
-                                                         "x limb-NTTs per launch)",
+                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the two kernels, "
+                                                         "profiles/r01_pmc_bench_kernels.json, scaled to this run's launches); below the "
+                                                         "algorithmic bytes because the transforms are fused",
                      "algorithmic_bytes_per_launch": ntt_bytes / launches if launches else None,
                      "launches": launches, "limb_ntts": limb_polys,
                      "avg_launch_ms": ntt_ms / launches if launches else None,

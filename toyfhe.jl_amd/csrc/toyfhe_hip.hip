@@ -321,7 +321,7 @@ int launch_bfv_core_fused(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64
     if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
     const unsigned items = (unsigned)(nct * sel.n);
     const unsigned grid = std::min(items, (unsigned)c->num_cus);
-    prof_begin(c, 0);
+    prof_begin(c, (int64_t)items * 7);  // limb transforms inside this launch: 4 forward + 3 inverse per item
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, Ea, Eb, T, scratch, c->limbs_dev, sel, items);
     prof_end(c);
     HIP_TRY(hipGetLastError());
@@ -606,7 +606,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         if (!fattr_set) { rc = set_lds(fk, lds); if (rc) return rc; fattr_set = true; }
         const unsigned items = (unsigned)(batch * level);
         const unsigned grid = std::min(items, (unsigned)c->num_cus);
-        prof_begin(c, 0);  // not an NTT launch for the roofline accounting: transforms, key products and additions are fused
+        prof_begin(c, (int64_t)items * (level + 2));  // limb transforms inside this launch: `level` forward + 2 inverse per item
         hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evk, ct, out, c->limbs_dev, A, Lk, items);
         prof_end(c);
         HIP_TRY(hipGetLastError());
