@@ -903,9 +903,10 @@ __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, con
         fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, 1u);
     }
 }
-// inverse transform of canonical residues held in the forward-last-pass register map; result (+ addend) to gdst
+// inverse transform of elements held in the forward-last-pass register map (v is reduced here and consumed); result
+// (+ addend) to gdst
 template <class A, int LOGB, int LOGT>
-__device__ __forceinline__ void fused_inv_from_regs(u64* lds, const u64* raw, u64* gdst, const typename A::ctx& C, const u64* addend) {
+__device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* v, u64* gdst, const typename A::ctx& C, const u64* addend) {
     constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB);
     constexpr int E = 1 << (LOGB - LOGT);
     const u32 tid = fresh_tid();
@@ -914,8 +915,9 @@ __device__ __forceinline__ void fused_inv_from_regs(u64* lds, const u64* raw, u6
     typedef pgeom<LOGB, LOGT, S1 - K2, K2> G2;
     typename A::tw tw_next[G2::SETS * G2::NTW];  // middle-pass twiddles, requested before the exchange
     {
-        typename A::elem v[E];
-        inv_compute<A, LOGB, LOGT, S1, KI1, true, true, 0>(v, raw, nullptr, C, tid, 1u);
+#pragma unroll
+        for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], C.p, C.pinv);
+        inv_compute<A, LOGB, LOGT, S1, KI1, true, true, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, 1u);
         if constexpr (S1 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S1 - K2, K2, false>(tw_next, C, tid, 1u);
         inv_store<A, LOGB, LOGT, S1, KI1, true, true>(v, lds, nullptr, C, tid);
     }
@@ -976,21 +978,27 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
                     const int e = u * G3::R + r;
                     const typename A::tw k1{fp_from_u64(e_masked[nat])}, k0{fp_from_u64(e_mask[nat])};
-                    acc[0][e] += fp_mulmod_c(v[e], k1, C.p, C.pinv);
-                    acc[1][e] += fp_mulmod_c(v[e], k0, C.p, C.pinv);
+                    // range: y reduced to |y| <= p/2, so every term is <= (1/2 + 0.75 a) p = 0.72 p and eight of them stay
+                    // below the 7.1 p exactness limit (fp64arith.h); the accumulators are swept every eighth digit
+                    const double y = fp_reduce(v[e], C.p, C.pinv);
+                    acc[0][e] += fp_mulmod_c(y, k1, C.p, C.pinv);
+                    acc[1][e] += fp_mulmod_c(y, k0, C.p, C.pinv);
+                }
+            }
+            if ((i & 7u) == 7u && i + 1 < level) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    acc[0][e] = fp_reduce(acc[0][e], C.p, C.pinv);
+                    acc[1][e] = fp_reduce(acc[1][e], C.p, C.pinv);
                 }
             }
         }
         // inverse transforms of the two accumulators; the first pass takes them from registers (same natural-order map)
 #pragma unroll
         for (int sidx = 0; sidx < 2; sidx++) {
-            const u32 tid = fresh_tid();
-            u64 raw[E];
-#pragma unroll
-            for (int e = 0; e < E; e++) raw[e] = fp_canon(acc[sidx][e], C.p, C.pinv);
             const u64* addend = (u32)sidx < add_s ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : nullptr;
             u64* gdst = out + ((size_t)((b * 2 + sidx) * level + j) << LOGB);
-            fused_inv_from_regs<A, LOGB, LOGT>(lds, raw, gdst, C, addend);
+            fused_inv_from_regs<A, LOGB, LOGT>(lds, acc[sidx], gdst, C, addend);
         }
     }
 }
@@ -1025,6 +1033,9 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
         u64* const t1 = T + (((size_t)(b * 3 + 1) * nb + j) << LOGB);
         u64* const t2 = T + (((size_t)(b * 3 + 2) * nb + j) << LOGB);
         typename A::elem A0[E], A1[E], v[E];
+        // range (fp64arith.h): the held transforms are reduced to |A| <= p/2; the running one stays lazy (|v| <= 5.7 p after the
+        // 4-stage last pass), so |A v| / p <= 2.85 p < 2^52 and a product is exact with |r| <= (1/2 + 1.5 a 2.85) p = 1.7 p;
+        // a0 b1 + a1 b0 <= 2.7 p; fused_inv_from_regs reduces before the inverse butterflies
         fused_fwd_to_regs<A, LOGB, LOGT>(lds, Ea + r0, C, first, A0);
 #pragma unroll
         for (int e = 0; e < E; e++) A0[e] = fp_reduce(A0[e], C.p, C.pinv);
@@ -1046,10 +1057,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
                     v[e] = fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv);                                // a0 b0, in place
                 }
             }
-            u64 raw[E];
-#pragma unroll
-            for (int e = 0; e < E; e++) raw[e] = fp_canon(v[e], C.p, C.pinv);
-            fused_inv_from_regs<A, LOGB, LOGT>(lds, raw, t0, C, nullptr);
+            fused_inv_from_regs<A, LOGB, LOGT>(lds, v, t0, C, nullptr);
         }
         fused_fwd_to_regs<A, LOGB, LOGT>(lds, Eb + r1, C, first, v);
         {
@@ -1066,18 +1074,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
                     A1[e] = fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv);
                 }
             }
-            {
-                u64 raw[E];
-#pragma unroll
-                for (int e = 0; e < E; e++) raw[e] = fp_canon(A0[e], C.p, C.pinv);
-                fused_inv_from_regs<A, LOGB, LOGT>(lds, raw, t1, C, nullptr);
-            }
-            {
-                u64 raw[E];
-#pragma unroll
-                for (int e = 0; e < E; e++) raw[e] = fp_canon(A1[e], C.p, C.pinv);
-                fused_inv_from_regs<A, LOGB, LOGT>(lds, raw, t2, C, nullptr);
-            }
+            fused_inv_from_regs<A, LOGB, LOGT>(lds, A0, t1, C, nullptr);
+            fused_inv_from_regs<A, LOGB, LOGT>(lds, A1, t2, C, nullptr);
         }
     }
 }

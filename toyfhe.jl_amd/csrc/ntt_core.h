@@ -465,7 +465,9 @@ constexpr inv_plan_t make_inv_plan() {
 }
 
 // Inverse butterflies (stage K-1 first).  Stages d >= K-PF come from `twp`; the others are loaded here.
-template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE, int PF, int USEL = -1, class HOOK = no_hook>
+// PRE: the operands are already in v as reduced elements (|v| <= p/2: the fused kernels' products) -- raw is not read
+template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE, int PF, int USEL = -1, class HOOK = no_hook,
+          bool PRE = false>
 TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
                          u32 pre, const HOOK& hook = HOOK()) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
@@ -478,7 +480,7 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
         typename A::elem* vv = v + u * G::R;
 #pragma unroll
         for (int r = 0; r < G::R; r++)
-            vv[r] = FROM_GLOBAL ? A::from_global(raw[u * G::R + r], C) : A::from_lds(raw[u * G::R + r]);
+            if (!PRE) vv[r] = FROM_GLOBAL ? A::from_global(raw[u * G::R + r], C) : A::from_lds(raw[u * G::R + r]);
 #pragma unroll
         for (int d = K - 1; d >= 0; d--) {
             const int half = 1 << (K - 1 - d);
