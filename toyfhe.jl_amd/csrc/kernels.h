@@ -926,7 +926,7 @@ __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Whole RNS-digit key switch (no special prime) for one (ciphertext b, limb j) per workgroup pass, fp64 policy,
+// Whole RNS-digit key switch for one (ciphertext b, working limb j) per workgroup pass, fp64 policy,
 // whole-transform blocks:   out_s[b][j] = c_s[b][j] + INTT_j( Σ_i evk_{i,s}[j] ⊙ NTT_j(lift_{i→j}(c_end[b][i])) )
 // The digit transforms never leave the CU: after the last forward pass each thread holds 2^(LOGB-LOGT) transform values
 // in registers, multiplies them by the two key components (streamed from L2; the key is shared by the whole batch) and
@@ -946,11 +946,13 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
     typedef pgeom<LOGB, LOGT, 0, K1> G1;
     typedef pgeom<LOGB, LOGT, K1 + K2, K3> G3;
     constexpr int E = G3::E;
-    const u32 level = (u32)KA.level, polys = (u32)KA.polys;
+    // special != 0 (ModulusRaised): the working limbs are the `level` ciphertext limbs plus the special prime (nw = level + 1);
+    // the transformed sums go to T [batch][2][nw][N] for k_ks_rescale_add instead of being added to c and written to out
+    const u32 level = (u32)KA.level, polys = (u32)KA.polys, nw = (u32)KA.nw;
     const u32 add_s = polys == 3 ? 2u : 1u;
     bool first = true;
     for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const u32 b = item / level, j = item % level;
+        const u32 b = item / nw, j = item % nw;
         const ntt_limb_t& Lj = LT[KA.w.idx[j]];
         const typename A::ctx C = A::make(Lj);
         lift_t lf;
@@ -996,8 +998,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
         // inverse transforms of the two accumulators; the first pass takes them from registers (same natural-order map)
 #pragma unroll
         for (int sidx = 0; sidx < 2; sidx++) {
-            const u64* addend = (u32)sidx < add_s ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : nullptr;
-            u64* gdst = out + ((size_t)((b * 2 + sidx) * level + j) << LOGB);
+            const u64* addend = (!KA.special && (u32)sidx < add_s) ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : nullptr;
+            u64* gdst = out + ((size_t)((b * 2 + sidx) * nw + j) << LOGB);
             fused_inv_from_regs<A, LOGB, LOGT>(lds, acc[sidx], gdst, C, addend);
         }
     }

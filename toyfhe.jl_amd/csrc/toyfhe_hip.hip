@@ -597,18 +597,26 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
     const u32 n = (u32)c->N;
     const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
     int rc;
-    if (!special && c->logN == 14 && c->variant == 0 && sel_fp(c, A.w, 0)) {
-        // everything in one kernel: digit lift, forward transforms, key inner product and the two inverse transforms
+    if (c->logN == 14 && c->variant == 0 && sel_fp(c, A.w, 0)) {
+        // everything in one kernel: digit lift, forward transforms, key inner product and the two inverse transforms;
+        // with the special prime the transformed sums go to S and the contraction kernel finishes (modulusraising.jl:42)
         constexpr int LOGT = logt_for(14);
         const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
         auto fk = k_ks_fused<ArithFp, 14, LOGT>;
         static bool fattr_set = false;
         if (!fattr_set) { rc = set_lds(fk, lds); if (rc) return rc; fattr_set = true; }
-        const unsigned items = (unsigned)(batch * level);
+        const unsigned items = (unsigned)(batch * nw);
         const unsigned grid = std::min(items, (unsigned)c->num_cus);
         prof_begin(c, (int64_t)items * (level + 2));  // limb transforms inside this launch: `level` forward + 2 inverse per item
-        hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evk, ct, out, c->limbs_dev, A, Lk, items);
+        hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evk, ct, special ? S : out, c->limbs_dev, A, Lk, items);
         prof_end(c);
+        HIP_TRY(hipGetLastError());
+        if (!special) return TFHE_OK;
+        rescale_arg_t ra;
+        memset(&ra, 0, sizeof ra);
+        const u64 P = c->q[Lk - 1];
+        for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+        hipLaunchKernelGGL(k_ks_rescale_add, dim3((unsigned)(batch * 2 * level)), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
