@@ -472,6 +472,35 @@ def test_full_size_bfv_mul_relin():
     assert np.array_equal(do2.to_numpy(got.shape), got[perm])
 
 
+def test_fused_pipeline_equals_three_kernel_pipeline():
+    """BASELINE configuration with more (ciphertext, limb) items than compute units: the fused kernels (k_bfv_core_fused,
+    k_ks_fused: several items per workgroup, ragged last chunk) against the separate transform / tensor / inner-product
+    kernels (NTT variant 3), bit for bit; both paths are checked against the oracle on small batches elsewhere."""
+    N, L, t = 1 << 14, 8, 65537
+    ch = H.chain(50, 17, N)
+    qs = ch[:L]
+    ctx = tf.Context(N, ch)
+    plan = tf.BfvPlan(ctx, ctx, t, idx_s=list(range(L)))
+    rng = np.random.default_rng(77)
+    batch = 70                                                   # 70 * 17 = 1190 core items, 560 key-switch items
+    c1, c2 = H.rand_residues(rng, qs, (batch, 2), N), H.rand_residues(rng, qs, (batch, 2), N)
+    evk = H.uniform_evk(rng, qs, L, N)
+    d1, d2, devk = dev(c1), dev(c2), dev(evk)
+    outs = {}
+    for variant, chunk in ((0, 48), (3, 48), (0, 256)):
+        ctx.set_ntt_variant(variant)
+        plan.set_chunk(chunk)
+        do = tf.DeviceBuffer(batch * 2 * L * N)
+        plan.mul_relin(devk.ptr, L, d1.ptr, d2.ptr, do.ptr, batch)
+        outs[(variant, chunk)] = do.to_numpy((batch, 2, L, N))
+    assert np.array_equal(outs[(0, 48)], outs[(3, 48)])
+    assert np.array_equal(outs[(0, 256)], outs[(3, 48)])
+    rs, rb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, ch)
+    pick = [0, 47, 48, batch - 1]
+    want = rs.keyswitch(L, False, evk, ref_cpu.bfv_mul(rs, rb, t, c1[pick], c2[pick]))
+    assert np.array_equal(outs[(0, 48)][pick], want)
+
+
 def test_full_size_ntt_properties():
     N, L = 1 << 14, 8
     qs = H.chain(50, L, N)
