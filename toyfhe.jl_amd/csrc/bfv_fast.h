@@ -144,7 +144,7 @@ TFHE_HD u64 mac_reduce(const u64 (&xi)[K], const u64* col, int stride, const bar
 
 // src: ℛ limb i of this coefficient at src[i*ls]; dst: ℛbig limb l at dst[l*ld]
 template <int NS, int NP, bool NARROW = false>
-TFHE_HD void bfv_expand_fast(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
+TFHE_HD void bfv_expand_fast(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld, bool copy_shared = true) {
     u64 x[NS], xi[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) {
@@ -154,8 +154,10 @@ TFHE_HD void bfv_expand_fast(const bfv_fast_tab_t& B, const u64* src, size_t ls,
     u64 frac;
     u32 alpha = conv_alpha_fast<NS>(xi, B.rho_q, B.sh_q, frac);
     if (frac + 2ull * NS < frac) alpha = conv_alpha_exact<NS>(xi, B.Mq, B.Aq, B.nwq, alpha);
+    if (copy_shared) {
 #pragma unroll
-    for (int i = 0; i < NS; i++) dst[(size_t)B.pos_s[i] * ld] = x[i];
+        for (int i = 0; i < NS; i++) dst[(size_t)B.pos_s[i] * ld] = x[i];
+    }
 #pragma unroll
     for (int j = 0; j < NP; j++) {
         const barrett_t& bt = B.pb[j];
@@ -224,7 +226,7 @@ TFHE_HD u32 conv_alpha_fp(const double (&xd)[K], const u64 (&xi)[K], const doubl
 }
 
 template <int NS, int NP>
-TFHE_HD void bfv_expand_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
+TFHE_HD void bfv_expand_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld, bool copy_shared = true) {
     static_assert(NS + 2 <= 16 && NP + 2 <= 16, "acc52 term budget");
     u64 x[NS], xi[NS];
     double xd[NS];
@@ -235,8 +237,10 @@ TFHE_HD void bfv_expand_narrow(const bfv_fast_tab_t& B, const u64* src, size_t l
         xi[i] = fp_to_u64(xd[i]);
     }
     const u32 alpha = conv_alpha_fp<NS>(xd, xi, B.f_qinv, B.Mq, B.Aq, B.nwq);
+    if (copy_shared) {
 #pragma unroll
-    for (int i = 0; i < NS; i++) dst[(size_t)B.pos_s[i] * ld] = x[i];
+        for (int i = 0; i < NS; i++) dst[(size_t)B.pos_s[i] * ld] = x[i];
+    }
 #pragma unroll
     for (int j = 0; j < NP; j++) {
         acc52 a{B.n_eNegHalf[j], 0, 0};

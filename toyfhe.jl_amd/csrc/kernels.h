@@ -1015,10 +1015,16 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 // round trip through a per-workgroup scratch row (L2 / Infinity Cache).  HBM traffic per limb: 4 rows read + 3 written
 // (+ 2 scratch) instead of 21 row moves for forward kernel + tensor kernel + inverse kernel.
 // ------------------------------------------------------------------------------------------------
+struct core_alt_t {  // limbs of ℛbig that are limbs of ℛ: read from the input ciphertexts ([nct][2][ns][N]) instead of E
+    const u64 *a, *b;
+    int ns;
+    signed char idx[TFHE_MAX_LIMBS];  // limb j of ℛbig -> limb of ℛ, or -1
+};
 template <class A, int LOGB, int LOGT>
 __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restrict__ Ea, const u64* __restrict__ Eb,
                                                                u64* __restrict__ T, u64* __restrict__ scratch,
-                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems) {
+                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems,
+                                                               core_alt_t alt) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     constexpr int K3 = LOGB - pass_k_fwd(LOGB, LOGT, 0) - pass_k_fwd(LOGB, LOGT, pass_k_fwd(LOGB, LOGT, 0));
     static_assert(pass_k_inv(LOGB, LOGT, LOGB) == K3, "forward last pass and inverse first pass must share the register map");
@@ -1038,13 +1044,18 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
         // range (fp64arith.h): the held transforms are reduced to |A| <= p/2; the running one stays lazy (|v| <= 5.7 p after the
         // 4-stage last pass), so |A v| / p <= 2.85 p < 2^52 and a product is exact with |r| <= (1/2 + 1.5 a 2.85) p = 1.7 p;
         // a0 b1 + a1 b0 <= 2.7 p; fused_inv_from_regs reduces before the inverse butterflies
-        fused_fwd_to_regs<A, LOGB, LOGT>(lds, Ea + r0, C, first, A0);
+        const u64 *pa0 = Ea + r0, *pa1 = Ea + r1, *pb0 = Eb + r0, *pb1 = Eb + r1;
+        if (alt.a && alt.idx[j] >= 0) {
+            const size_t s0 = ((size_t)(b * 2 + 0) * alt.ns + alt.idx[j]) << LOGB, s1 = ((size_t)(b * 2 + 1) * alt.ns + alt.idx[j]) << LOGB;
+            pa0 = alt.a + s0; pa1 = alt.a + s1; pb0 = alt.b + s0; pb1 = alt.b + s1;
+        }
+        fused_fwd_to_regs<A, LOGB, LOGT>(lds, pa0, C, first, A0);
 #pragma unroll
         for (int e = 0; e < E; e++) A0[e] = fp_reduce(A0[e], C.p, C.pinv);
-        fused_fwd_to_regs<A, LOGB, LOGT>(lds, Ea + r1, C, first, A1);
+        fused_fwd_to_regs<A, LOGB, LOGT>(lds, pa1, C, first, A1);
 #pragma unroll
         for (int e = 0; e < E; e++) A1[e] = fp_reduce(A1[e], C.p, C.pinv);
-        fused_fwd_to_regs<A, LOGB, LOGT>(lds, Eb + r0, C, first, v);
+        fused_fwd_to_regs<A, LOGB, LOGT>(lds, pb0, C, first, v);
         {
             const u32 tid = fresh_tid();
 #pragma unroll
@@ -1061,7 +1072,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
             }
             fused_inv_from_regs<A, LOGB, LOGT>(lds, v, t0, C, nullptr);
         }
-        fused_fwd_to_regs<A, LOGB, LOGT>(lds, Eb + r1, C, first, v);
+        fused_fwd_to_regs<A, LOGB, LOGT>(lds, pb1, C, first, v);
         {
             const u32 tid = fresh_tid();
 #pragma unroll
@@ -1166,14 +1177,16 @@ __global__ __launch_bounds__(BFV_BS) void k_bfv_contract(const u64* __restrict__
 }
 
 // register-resident fast path (bfv_fast.h): ℛbig = ℛ ∪ P with compile-time limb counts
+// copy_shared = 0: the limbs ℛbig shares with ℛ are not written -- k_bfv_core_fused transforms them straight out of the
+// input ciphertexts
 template <int NS, int NP>
 __global__ __launch_bounds__(256) void k_bfv_expand_fast(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                          const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx) {
+                                                          const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx, int copy_shared) {
     const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
     const size_t p = blockIdx.x / gx;
     if (k >= n) return;
-    if (Bt->narrow) bfv_expand_narrow<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n);
-    else bfv_expand_fast<NS, NP, false>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n);
+    if (Bt->narrow) bfv_expand_narrow<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
+    else bfv_expand_fast<NS, NP, false>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
 }
 template <int NS, int NP>
 __global__ __launch_bounds__(256) void k_bfv_contract_fast(const u64* __restrict__ src, u64* __restrict__ dst,

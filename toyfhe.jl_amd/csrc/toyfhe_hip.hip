@@ -309,9 +309,11 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
     return TFHE_OK;
 }
 
+bool bfv_core_fusable(const tfhe_ctx* c, const limb_sel_t& sel) { return c->variant == 0 && c->logN == 14 && sel_fp(c, sel, 0); }
 // forward transforms + tensor + inverse transforms of one BFV multiplication chunk in one kernel (fp64 policy, N = 2^14);
 // *done = false when the configuration is not covered.  scratch: one row per workgroup.
-int launch_bfv_core_fused(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64* scratch, int64_t nct, const limb_sel_t& sel, bool* done) {
+int launch_bfv_core_fused(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64* scratch, int64_t nct, const limb_sel_t& sel, bool* done,
+                          const core_alt_t* altp = nullptr) {
     *done = false;
     if (c->variant != 0 || c->logN != 14 || !sel_fp(c, sel, 0) || nct * sel.n > 0x7fffffffll) return TFHE_OK;
     constexpr int LOGT = logt_for(14);
@@ -322,7 +324,9 @@ int launch_bfv_core_fused(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64
     const unsigned items = (unsigned)(nct * sel.n);
     const unsigned grid = std::min(items, (unsigned)c->num_cus);
     prof_begin(c, (int64_t)items * 7);  // limb transforms inside this launch: 4 forward + 3 inverse per item
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, Ea, Eb, T, scratch, c->limbs_dev, sel, items);
+    core_alt_t alt;
+    if (altp) alt = *altp; else { memset(&alt, 0, sizeof alt); alt.a = alt.b = nullptr; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, Ea, Eb, T, scratch, c->limbs_dev, sel, items, alt);
     prof_end(c);
     HIP_TRY(hipGetLastError());
     *done = true;
