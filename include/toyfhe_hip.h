@@ -59,9 +59,9 @@ int tfhe_ctx_set_stream(tfhe_ctx *ctx, void *hip_stream /* hipStream_t, NULL = l
 int tfhe_ctx_sync(tfhe_ctx *ctx);
 /* choose the NTT kernel family: 0 = auto (register-blocked LDS kernel; exact-integer fp64 butterflies
  * when every selected modulus is < 1.125*2^50, u64 Shoup butterflies otherwise), 1 = force the generic
- * radix-2 kernel, 2 = force the u64 register-blocked kernel, 3 = fp64 kernels without the next-row overlap (LDS-DMA
- * staging in the inverse, register prefetch in the forward) and without the read-once digit lift -- 1, 2 and 3 are
- * cross-check paths for tests */
+ * radix-2 kernel, 2 = force the u64 register-blocked kernel, 3 = fp64 kernels one operation per launch: no fused
+ * BFV core / key-switch kernels, no next-row overlap (LDS-DMA staging in the inverse, register prefetch in the
+ * forward), no read-once digit lift -- 1, 2 and 3 are cross-check paths for tests */
 int tfhe_ctx_set_ntt_variant(tfhe_ctx *ctx, int variant);
 
 /* ---- device memory helpers (for callers without a GPU array package) ------------------------- */
