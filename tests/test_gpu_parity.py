@@ -293,6 +293,25 @@ def test_keyswitch_window_matches_oracle(N, bits, L, w):
         ctx.keyswitch_window(L, w, devk.ptr, nwin, devk.ptr, 4, devk.ptr, 1)           # rlwe_she.jl:318
 
 
+@pytest.mark.parametrize("special", [False, True])
+def test_rotate_full_degree_matches_oracle(special):
+    """rotate = keyswitch o apply_galois_element (rlwe_she.jl:355-359) at N = 2^14 -- the fused key-switch kernel behind the
+    Galois permutation, with and without the special prime -- against the oracle composition."""
+    N, Lk = 1 << 14, 4
+    qs = H.chain(50, Lk, N)
+    level = Lk - 1 if special else Lk
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(14 + special)
+    evk = H.uniform_evk(rng, qs, Lk, N)
+    ct = H.rand_residues(rng, qs[:level], (3, 2), N)
+    g = pow(3, 5, 2 * N)
+    devk, dct, dout = dev(evk), dev(ct), tf.DeviceBuffer(3 * 2 * level * N)
+    ctx.rotate(Lk, level, special, devk.ptr, Lk, g, dct.ptr, dout.ptr, 3)
+    rot = ref.galois(g, ct, idx=list(range(level)))
+    want = ref.keyswitch(level, special, evk, rot)
+    assert np.array_equal(dout.to_numpy(want.shape), want)
+
+
 def test_golden_keyswitch_and_rotate():
     ctx = tf.Context(32, G["ksS_q"])
     devk, dct = dev(G["ksS_evk_ntt"]), dev(G["ksS_ct"])
