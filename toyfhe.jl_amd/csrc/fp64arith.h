@@ -12,9 +12,9 @@
 // A twiddle is ONE double (8 bytes in the table, 2 VGPRs).  Values are kept as signed lazy
 // representatives; `reduce` brings |v| back to <= p/2 (+ tiny).
 // Range bookkeeping (in units of p, a = p 2^-52 <= 0.28125, growth per forward stage b' = b (1 + 1.5 a) + 1/2):
-//   forward, from |v| <= 1/2 (LDS values are reduced, global inputs are centred):
-//        1.21, 2.22, 3.66, 5.70 after 1..4 stages  < 2^53 / p >= 7.1;  5-stage passes reduce after stage 3
-//        (a 5-stage first pass may also start from uncentred residues: 1 -> 1.92 -> 3.23 -> 5.10, sweep, ...)
+//   forward: residues enter uncentred (|v| <= 1); a sweep (reduce everything to <= 1/2) is planned before the first stage
+//        that would pass 7 (2^53 / p >= 7.1), across pass boundaries -- LDS holds lazy doubles (ntt_core.h
+//        fp_fwd_sweep_before):  1.92 3.23 5.09 | 1.21 2.22 3.66 5.70 | 1.21 ...  = one sweep per four stages
 //   inverse: sums double per stage, products return to <= 1/2 + 1.5 a b; only the operands whose sum would pass 7 p are
 //        reduced, by a compile-time plan (ntt_core.h make_inv_plan)
 #pragma once

@@ -156,6 +156,7 @@ struct ArithInt {
         x = shoup_lazy(a, c.ninv, c.q);
         y = shoup_lazy(d, c.w1n, c.q);
     }
+    static constexpr bool fwd_sweep_before(int, int) { return false; }  // Harvey butterflies keep [0, 4q) by themselves
     static TFHE_HD void range_fwd(elem&, const ctx&) {}
     static TFHE_HD void range_inv(elem&, const ctx&) {}
     static TFHE_HD u64 out_fwd(elem v, const ctx& c) { return csub(csub(v, 2 * c.q), c.q); }
@@ -163,8 +164,24 @@ struct ArithInt {
     static TFHE_HD u64 out_inv_lazy(elem v, const ctx&) { return v; }  // [0,2q) for the top kernel
 };
 
+// Forward range plan of the fp64 policy (fp64arith.h): a block's residues enter with |v| <= p (uncentred, or a loosely
+// lifted digit), every stage maps the bound b to b (1 + 1.5 a) + 1/2 with a = 0.28125, and a sweep (reduce every element
+// to |v| <= p/2) is placed before the first stage that would pass 7 p (exactness limit 2^53 / p >= 7.11).  The plan runs
+// over the block's stages regardless of the pass boundaries -- LDS holds lazy doubles -- which gives one sweep per four
+// stages: before stages 3, 7, 11 of a 2^14 block (bounds 1.92 3.23 5.09 | 1.21 2.22 3.66 5.70 | ...), and 3.66 p at the end.
+constexpr bool fp_fwd_sweep_before(int nstages, int s) {
+    double b = 1.0;
+    for (int t = 0; t < nstages; t++) {
+        const bool sweep = b * 1.421875 + 0.5 > 7.0;
+        if (t == s) return sweep;
+        if (sweep) b = 0.5001;
+        b = b * 1.421875 + 0.5;
+    }
+    return false;
+}
 struct ArithFp {
     static constexpr bool prefetch_tw = true;
+    static constexpr bool fwd_sweep_before(int nstages, int s) { return fp_fwd_sweep_before(nstages, s); }
     typedef double elem;
     typedef ftw_t tw;
     struct ctx {
@@ -324,7 +341,7 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
     const bool use_b = LAST && pre == 1u && A::has_b(C);  // permuted boundary table of whole-transform blocks
     if (FIRST && lift) {  // digit lift: all conversions first, then the butterflies (register pressure)
 #pragma unroll
-        for (int i = 0; i < G::E; i++) v[i] = A::from_global_lift(raw[i], C, *lift, K >= 5);
+        for (int i = 0; i < G::E; i++) v[i] = A::from_global_lift(raw[i], C, *lift, true);
         TFHE_SCHED_FENCE();
     }
 #pragma unroll
@@ -336,14 +353,16 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
 #pragma unroll
         for (int r = 0; r < G::R; r++) {
             if (FIRST && lift) continue;
-            // 5-stage first passes sweep the range after their third stage, so residues may enter uncentred (|v| < p:
-            // 1 -> 1.92 -> 3.23 -> 5.10 p, fp64arith.h); 4-stage passes have no sweep and need |v| <= p/2
-            vv[r] = FIRST ? (K >= 5 ? A::from_global_plain(raw[u * G::R + r], C) : A::from_global(raw[u * G::R + r], C))
-                          : A::from_lds(raw[u * G::R + r]);
+            // residues enter uncentred (|v| < p); the policy's range plan places the sweeps (fp_fwd_sweep_before)
+            vv[r] = FIRST ? A::from_global_plain(raw[u * G::R + r], C) : A::from_lds(raw[u * G::R + r]);
         }
 #pragma unroll
         for (int d = 0; d < K; d++) {
             const int half = 1 << (K - 1 - d);
+            if (A::fwd_sweep_before(LOGB, S0 + d)) {  // range control (fp64 budget; never for u64)
+#pragma unroll
+                for (int r = 0; r < G::R; r++) A::range_fwd(vv[r], C);
+            }
 #pragma unroll
             for (int g = 0; g < (1 << d); g++) {
                 const typename A::tw w = d < PF ? twp[u * G::NTW + (1 << d) - 1 + g]
@@ -355,10 +374,6 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
                     A::bf_fwd(vv[r0], vv[r0 + half], w, C);
                 }
                 hook(((u * K + d) * (G::R / 2)) + g * half, ((u * K + d) * (G::R / 2)) + (g + 1) * half, G::SETS * K * (G::R / 2));
-            }
-            if (K >= 5 && d == 2) {  // range control inside 5-stage passes (fp64 budget; no-op for u64)
-#pragma unroll
-                for (int r = 0; r < G::R; r++) A::range_fwd(vv[r], C);
             }
         }
     }
@@ -380,8 +395,7 @@ TFHE_HD void fwd_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
                 const u32 nat = (brev_bits((u32)r, K) << (LOGB - K)) + c0;  // brv_LOGB(block-local position)
                 gdst[((u64)nat << x) + sb_rev] = A::out_fwd(e, C);
             } else {
-                A::range_fwd(e, C);
-                lds[pb + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)] = A::to_lds(e);
+                lds[pb + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)] = A::to_lds(e);  // lazy (the range plan spans the passes)
             }
         }
     }
