@@ -89,13 +89,35 @@ __device__ __forceinline__ void inv_schedule(u64* lds, const u64* gsrc, u64* gds
 
 // Workgroups loop over items i = blockIdx.x, blockIdx.x + gridDim.x, ... (item = (row << x) + sb, row = poly*limbs + j
 // in the plain mode; see ntt_io_t for the grouped / digit-lift / addend row maps).
+// Item walk of the block kernels for N > 2^LOGB (x > 0).  The 2^x sub-blocks of a row interleave in the row's natural
+// order at 8-byte granularity (forward output / inverse input at stride 2^x), so every 128-byte line is shared by 2^x
+// sub-blocks.  Workgroups are dispatched to the 8 XCDs round-robin (workgroup b -> XCD b % 8); the walk gives the
+// sub-blocks of one row to workgroups of ONE XCD in the same iteration, so the partial lines meet in that XCD's L2
+// (stores merge before write-back, loads hit after the first miss) instead of crossing the fabric 2^x times.
+// Returns the item ((row << x) | sub-block) for position `it` of workgroup `b`, or ~0u past the end; identity when the
+// grid does not tile.
+__device__ __forceinline__ u32 xcd_walk_item(u32 it, u32 b, u32 grid, int x, u32 nitems) {
+    const u32 nsb = 1u << x;
+    if (x == 0 || (grid % (8u * nsb)) != 0u) {
+        const u32 item = it * grid + b;
+        return item < nitems ? item : ~0u;
+    }
+    const u32 xcd = b & 7u, slot = b >> 3, groups = (grid >> 3) >> x;
+    const u32 row = it * (8u * groups) + xcd * groups + (slot >> x);
+    const u32 item = (row << x) | (slot & (nsb - 1u));
+    return item < nitems ? item : ~0u;
+}
 template <class A, int LOGB, int LOGT, int IOMODE>
 __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_block(const u64* __restrict__ src, u64* __restrict__ dst,
                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
                                                               u32 nitems, ntt_io_t io) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const size_t ntot = (size_t)1 << (LOGB + x);
-    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const u32 niter = (nitems + gridDim.x - 1) / gridDim.x;
+    bool first = true;
+    for (u32 it = 0; it < niter; it++) {
+        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x, nitems);
+        if (item == ~0u) continue;
         const u32 sb = item & ((1u << x) - 1), pl = item >> x;
         u32 srow = pl, drow = pl, j = pl % (u32)sel.n;
         lift_t lf;
@@ -110,7 +132,8 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_block(con
             lift = &lf;
         }
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
-        if (item != blockIdx.x) __syncthreads();  // the previous item's last pass has read LDS
+        if (!first) __syncthreads();  // the previous item's last pass has read LDS
+        first = false;
         fwd_schedule<A, LOGB, LOGT, 0>(lds, src + srow * ntot + ((size_t)sb << LOGB), dst + drow * ntot, C, fresh_tid(),
                                        (1u << x) + sb, x, brev_bits(sb, x), lift);
     }
@@ -242,7 +265,11 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restri
                                                               u32 nitems, ntt_io_t io) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const size_t ntot = (size_t)1 << (LOGB + x);
-    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const u32 niter = (nitems + gridDim.x - 1) / gridDim.x;
+    bool first = true;
+    for (u32 it = 0; it < niter; it++) {
+        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x, nitems);
+        if (item == ~0u) continue;
         const u32 sb = item & ((1u << x) - 1), pl = item >> x;
         u32 srow = pl, drow = pl, j = pl % (u32)sel.n;
         const u64* addend = nullptr;
@@ -254,7 +281,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restri
             if (w < io.add_rows) addend = io.addend + (size_t)(g * io.add_gstride + w) * ntot;
         }
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
-        if (item != blockIdx.x) __syncthreads();
+        if (!first) __syncthreads();
+        first = false;
         if (A::prefetch_tw && x == 0) {  // fp64 policy, whole transform: 8-byte twiddles prefetched a pass ahead
             if constexpr (A::prefetch_tw)
                 inv_schedule_ptw<A, LOGB, LOGT, LOGB>(lds, src + srow * ntot, dst + drow * ntot, C, fresh_tid(), 1u, addend, nullptr);
