@@ -122,6 +122,39 @@ def test_nntt_2_15_many_rows_single_kernel():
         assert np.array_equal(run_ntt(ctx, want, inverse=True, idx=[0]), a), variant
 
 
+@pytest.mark.parametrize("logn,rows", [(16, 2 * 256 + 7), (17, 256 + 5)])
+def test_nntt_2_16_17_many_rows_subblock_walk(logn, rows):
+    """N >= 2^16 with more rows than compute units: the sub-block kernels walk their items XCD-aware and (fp64 policy)
+    take two sub-blocks per workgroup with 16-byte pieces on the natural-order side; every row must still land where
+    the oracle puts it, and the u64 one-sub-block path (variant 2) must agree."""
+    N = 1 << logn
+    qs = H.chain(50, 2, N)
+    rng = np.random.default_rng(logn)
+    a = H.rand_residues(rng, qs, (rows,), N)        # rows alternate over both limbs inside the kernels
+    a[0, 0, :4] = [0, 1, qs[0] - 1, qs[0] // 2]
+    want = ref_cpu.RefCtx(N, qs).nntt(a)
+    ctx = tf.Context(N, qs)
+    for variant in (0, 2):
+        ctx.set_ntt_variant(variant)
+        assert np.array_equal(run_ntt(ctx, a), want), variant
+        assert np.array_equal(run_ntt(ctx, want, inverse=True), a), variant
+    # out of place (N = 2^16: the one-kernel forward path, which reads the source row from two workgroups)
+    ctx.set_ntt_variant(0)
+    d_in, d_out = dev(a), tf.DeviceBuffer(a.size)
+    ctx.nntt(d_in.ptr, d_out.ptr, rows, 2)
+    assert np.array_equal(d_out.to_numpy(a.shape), want)
+    assert np.array_equal(d_in.to_numpy(a.shape), a)
+    ctx.inntt(d_out.ptr, d_in.ptr, rows, 2)
+    assert np.array_equal(d_in.to_numpy(a.shape), a)
+    # rows that start 8 bytes off a 16-byte boundary: the paired kernels do not apply, the result must not change
+    few = a[:3]
+    pad = tf.DeviceBuffer.from_numpy(np.concatenate([[0], few.ravel(), [0]]).astype(np.uint64))
+    ctx.nntt(pad.ptr + 8, pad.ptr + 8, 3, 2)
+    assert np.array_equal(pad.to_numpy((few.size + 2,))[1:-1].reshape(few.shape), want[:3])
+    ctx.inntt(pad.ptr + 8, pad.ptr + 8, 3, 2)
+    assert np.array_equal(pad.to_numpy((few.size + 2,))[1:-1].reshape(few.shape), few)
+
+
 def test_nntt_limb_selection_and_explicit_psi():
     N = 2048
     q, psi = 1152921504606830593, 811032584449645127    # cryptparams.jl:25

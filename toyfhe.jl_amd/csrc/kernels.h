@@ -588,6 +588,223 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_pair(const u64* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sub-block kernels for N = 2^(LOGB+x), x >= 2 (after / before the k_ntt_*_top stages): one workgroup runs the TWO
+// sub-blocks sb and sb + 2^(x-1) of a row one after the other.  Their words are neighbours on the natural-order side
+// (positions (nat << x) + brv_x(sb) and + 1), so that side moves as 16-byte pieces -- half as many partial-line
+// transactions as one sub-block per workgroup, and a line is shared by 2^(x-1) workgroups (of one XCD: xcd_walk_item).
+//   forward: the first sub-block's canonical outputs wait in registers (64 VGPRs) for the second's;
+//   inverse: both sub-blocks' inputs are read together, the second's wait in registers.
+// ------------------------------------------------------------------------------------------------
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_subpair(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                                const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
+                                                                u32 nitems) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
+    static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass schedule expected");
+    typedef pgeom<LOGB, LOGT, K1 + K2, K3> G3;
+    constexpr int E = G3::E;
+    const size_t ntot = (size_t)1 << (LOGB + x);
+    const u32 niter = (nitems + gridDim.x - 1) / gridDim.x, hmask = (1u << (x - 1)) - 1u;
+    bool first = true;
+    for (u32 it = 0; it < niter; it++) {
+        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x - 1, nitems);
+        if (item == ~0u) continue;
+        const u32 ph = item & hmask, pl = item >> (x - 1);
+        const typename A::ctx C = A::make(LT[sel.idx[pl % (u32)sel.n]]);
+        u64* d = dst + pl * ntot + brev_bits(ph, x);  // even word offset: 16-byte aligned pieces
+        u64 held[E];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const u32 sb = ph + ((u32)half << (x - 1)), pre = (1u << x) + sb;
+            const u64* g = src + pl * ntot + ((size_t)sb << LOGB);
+            const u32 tid = fresh_tid();
+            if (!first) __syncthreads();  // the previous transform's last pass has read LDS
+            first = false;
+            ntt_fwd_pass<A, LOGB, LOGT, 0, K1, true, false>(lds, g, nullptr, C, tid, pre, 0, 0u);
+            __syncthreads();
+            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            __syncthreads();
+            {
+                u64 r3[E];
+                typename A::elem v[E];
+                fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
+                fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, pre);
+#pragma unroll
+                for (int u = 0; u < G3::SETS; u++) {
+                    u32 c0, hi, base;
+                    G3::template coords<true>(tid, u, c0, hi, base);
+#pragma unroll
+                    for (int r = 0; r < G3::R; r++) {
+                        const int e = u * G3::R + r;
+                        const u64 o = A::out_fwd(v[e], C);
+                        if (half == 0) {
+                            held[e] = o;
+                        } else {
+                            const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
+                            u64x2_t w;
+                            w.x = held[e];
+                            w.y = o;
+                            *(u64x2_t*)(d + ((u64)nat << x)) = w;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+// N = 2^(LOGB+2), forward, fp64 policy, ONE kernel: the workgroup reads all four quarters of the row, forms the first-pass
+// operands of its two sub-blocks (sb = ph and ph + 2: two of the four outputs of the two top stages, 4 modular products
+// per point instead of the 2 a full radix-4 would spend on them) and runs them as in k_ntt_fwd_subpair.  The row's other
+// workgroup (same XCD, same iteration: xcd_walk_item) reads the same lines from L2 -- one HBM read and one write of the
+// row instead of two of each with k_ntt_fwd_top in front.
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int x = 2;
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
+    static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass schedule expected");
+    typedef pgeom<LOGB, LOGT, K1 + K2, K3> G3;
+    constexpr int E = G3::E;
+    const size_t ntot = (size_t)1 << (LOGB + x);
+    const u32 niter = (nitems + gridDim.x - 1) / gridDim.x;
+    bool first = true;
+    for (u32 it = 0; it < niter; it++) {
+        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x - 1, nitems);
+        if (item == ~0u) continue;
+        const u32 ph = item & 1u, pl = item >> 1;
+        const typename A::ctx C = A::make(LT[sel.idx[pl % (u32)sel.n]]);
+        const u64* s = src + pl * ntot;
+        u64* d = dst + pl * ntot + brev_bits(ph, x);
+        u64 w[2][E];  // the two sub-blocks' first-pass operands (element bits)
+        {
+            const u32 tid = fresh_tid();
+            const typename A::tw w1 = A::ld_fwd(C, 1u), w2 = A::ld_fwd(C, 2u), w3 = A::ld_fwd(C, 3u);
+            const double sgn = ph ? -1.0 : 1.0;
+#pragma unroll
+            for (int h = 0; h < 4; h++) {  // in quarters: bounds the raw operands in flight next to the 128 result registers
+                u64 q[4][E / 4];
+#pragma unroll
+                for (int r = 0; r < E / 4; r++) {
+                    const u32 j = tid + ((u32)(h * (E / 4) + r) << LOGT);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) q[k][r] = s[j + ((u32)k << LOGB)];
+                }
+                TFHE_SCHED_FENCE();
+#pragma unroll
+                for (int r = 0; r < E / 4; r++) {
+                    const double x0 = fp_from_u64(q[0][r]), x1 = fp_from_u64(q[1][r]);
+                    const double t2 = fp_mulmod_c(fp_from_u64(q[2][r]), w1, C.p, C.pinv);
+                    const double t3 = fp_mulmod_c(fp_from_u64(q[3][r]), w1, C.p, C.pinv);
+                    // |y| <= 1.92 p, products <= 1.31 p (fp64arith.h); the sub-blocks take reduced operands
+                    const double u0 = fp_mulmod_c(x1 + t3, w2, C.p, C.pinv), u1 = fp_mulmod_c(x1 - t3, w3, C.p, C.pinv);
+                    w[0][h * (E / 4) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u0, x0 + t2), C.p, C.pinv));
+                    w[1][h * (E / 4) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u1, x0 - t2), C.p, C.pinv));
+                }
+                TFHE_SCHED_FENCE();
+            }
+        }
+        u64 held[E];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const u32 sb = ph + ((u32)half << (x - 1)), pre = (1u << x) + sb;
+            const u32 tid = fresh_tid();
+            if (!first) __syncthreads();  // the previous transform's last pass has read LDS
+            first = false;
+            {
+                typename A::elem v[E];
+                fwd_compute<A, LOGB, LOGT, 0, K1, false, false, 0>(v, w[half], nullptr, C, tid, pre);
+                fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+            }
+            __syncthreads();
+            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            __syncthreads();
+            {
+                u64 r3[E];
+                typename A::elem v[E];
+                fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
+                fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, pre);
+#pragma unroll
+                for (int u = 0; u < G3::SETS; u++) {
+                    u32 c0, hi, base;
+                    G3::template coords<true>(tid, u, c0, hi, base);
+#pragma unroll
+                    for (int r = 0; r < G3::R; r++) {
+                        const int e = u * G3::R + r;
+                        const u64 o = A::out_fwd(v[e], C);
+                        if (half == 0) {
+                            held[e] = o;
+                        } else {
+                            const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
+                            u64x2_t ww;
+                            ww.x = held[e];
+                            ww.y = o;
+                            *(u64x2_t*)(d + ((u64)nat << x)) = ww;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_subpair(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                                const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
+                                                                u32 nitems) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_inv(LOGB, LOGT, LOGB), S1 = LOGB - K1;
+    typedef pgeom<LOGB, LOGT, S1, K1> G1;
+    constexpr int E = G1::E;
+    constexpr int K2 = pass_k_inv(LOGB, LOGT, S1), KL = S1 - K2;  // middle and last pass widths
+    static_assert(KL >= 1 && pass_k_inv(LOGB, LOGT, KL) == KL, "three-pass schedule expected");
+    const size_t ntot = (size_t)1 << (LOGB + x);
+    const u32 niter = (nitems + gridDim.x - 1) / gridDim.x, hmask = (1u << (x - 1)) - 1u;
+    bool first = true;
+    for (u32 it = 0; it < niter; it++) {
+        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x - 1, nitems);
+        if (item == ~0u) continue;
+        const u32 ph = item & hmask, pl = item >> (x - 1);
+        const typename A::ctx C = A::make(LT[sel.idx[pl % (u32)sel.n]]);
+        const u64* s = src + pl * ntot + brev_bits(ph, x);
+        u64 raw[2][E];
+        {
+            const u32 tid = fresh_tid();
+#pragma unroll
+            for (int u = 0; u < G1::SETS; u++) {
+                u32 c0, hi, base;
+                G1::template coords<true>(tid, u, c0, hi, base);
+#pragma unroll
+                for (int r = 0; r < G1::R; r++) {
+                    const u32 nat = (brev_bits((u32)r, K1) << (LOGB - K1)) + c0;
+                    const u64x2_t w = *(const u64x2_t*)(s + ((u64)nat << x));
+                    raw[0][u * G1::R + r] = w.x;
+                    raw[1][u * G1::R + r] = w.y;
+                }
+            }
+            TFHE_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const u32 sb = ph + ((u32)half << (x - 1)), pre = (1u << x) + sb;
+            u64* g = dst + pl * ntot + ((size_t)sb << LOGB);
+            const u32 tid = fresh_tid();
+            if (!first) __syncthreads();
+            first = false;
+            {
+                typename A::elem v[E];
+                inv_compute<A, LOGB, LOGT, S1, K1, true, false, 0>(v, raw[half], nullptr, C, tid, pre);
+                inv_store<A, LOGB, LOGT, S1, K1, true, false>(v, lds, nullptr, C, tid);
+            }
+            __syncthreads();
+            ntt_inv_pass<A, LOGB, LOGT, KL, K2, false, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            __syncthreads();
+            ntt_inv_pass<A, LOGB, LOGT, 0, KL, false, true, false>(lds, nullptr, g, C, tid, pre, 0, 0u);
+        }
+    }
+}
+
 // top stages of N > 2^LOGB transforms: one column per thread, rows = count*limbs
 template <int X>
 __global__ __launch_bounds__(256) void k_ntt_fwd_top(const u64* __restrict__ src, u64* __restrict__ dst,

@@ -216,6 +216,30 @@ int launch_block_inv(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const 
     return TFHE_OK;
 }
 
+// sub-blocks of N >= 2^16 rows, two per workgroup (k_ntt_*_subpair); plain I/O, 16-byte aligned rows
+template <class A>
+int launch_subpair(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x) {
+    constexpr int LOGB = 14, LOGT = logt_for(LOGB);
+    const size_t lds = (size_t)lds_words<LOGB, LOGT>() * 8;
+    auto fk = k_ntt_fwd_subpair<A, LOGB, LOGT>;
+    auto ik = k_ntt_inv_subpair<A, LOGB, LOGT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = set_lds(fk, lds);
+        if (!rc) rc = set_lds(ik, lds);
+        if (rc) return rc;
+        attr_set = true;
+    }
+    const unsigned items = (unsigned)(rows << (x - 1));
+    const unsigned grid = std::min(items, (unsigned)c->num_cus);
+    prof_begin(c, rows);
+    if (inverse) hipLaunchKernelGGL(ik, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items);
+    else hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items);
+    prof_end(c);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
 int launch_generic(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, const ntt_io_t& io) {
     const size_t lds = (size_t)c->N * 8;
     static bool attr_set = false;
@@ -280,6 +304,24 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
         return TFHE_OK;
     }
     if (x > 3) return fail(TFHE_E_UNSUPPORTED, "N = 2^%d not supported (max 2^17)", n);
+    // fp64 policy: two sub-blocks per workgroup (16-byte pieces on the natural-order side)
+    const bool pairable = x >= 2 && c->variant == 0 && sel_fp(c, sel, x) && (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0;
+    if (!inverse && pairable && x == 2 && src != dst) {
+        // N = 2^16 forward in one kernel: top stages folded into the paired sub-block kernel (out of place only: the
+        // row's other workgroup reads the same source words)
+        constexpr int LOGT = logt_for(14);
+        const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
+        auto qk = k_ntt_fwd_quad<ArithFp, 14, LOGT>;
+        static bool qattr_set = false;
+        if (!qattr_set) { int rc2 = set_lds(qk, lds); if (rc2) return rc2; qattr_set = true; }
+        const unsigned items = (unsigned)(rows << 1);
+        const unsigned grid = std::min(items, (unsigned)c->num_cus);
+        prof_begin(c, rows);
+        hipLaunchKernelGGL(qk, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, items);
+        prof_end(c);
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
     void* tmp = nullptr;
     int rc = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
     if (rc) return rc;
@@ -294,9 +336,11 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
         }
         prof_end(c);
         HIP_TRY(hipGetLastError());
+        if (pairable) return launch_subpair<ArithFp>(c, false, t, dst, rows, sel, x);
         return sel_fp(c, sel, x) ? launch_block_fwd<ArithFp, 14>(c, t, dst, rows, sel, x, io) : launch_block_fwd<ArithInt, 14>(c, t, dst, rows, sel, x, io);
     }
-    rc = sel_fp(c, sel, x) ? launch_block_inv<ArithFp, 14>(c, src, t, rows, sel, x, io) : launch_block_inv<ArithInt, 14>(c, src, t, rows, sel, x, io);
+    if (pairable) rc = launch_subpair<ArithFp>(c, true, src, t, rows, sel, x);
+    else rc = sel_fp(c, sel, x) ? launch_block_inv<ArithFp, 14>(c, src, t, rows, sel, x, io) : launch_block_inv<ArithInt, 14>(c, src, t, rows, sel, x, io);
     if (rc) return rc;
     prof_begin(c, 0);
     switch (x) {
