@@ -683,25 +683,26 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
             const u32 tid = fresh_tid();
             const typename A::tw w1 = A::ld_fwd(C, 1u), w2 = A::ld_fwd(C, 2u), w3 = A::ld_fwd(C, 3u);
             const double sgn = ph ? -1.0 : 1.0;
+            constexpr int QC = 4;  // pieces of the load phase
 #pragma unroll
-            for (int h = 0; h < 4; h++) {  // in quarters: bounds the raw operands in flight next to the 128 result registers
-                u64 q[4][E / 4];
+            for (int h = 0; h < QC; h++) {  // in pieces: bounds the raw operands in flight next to the 128 result registers
+                u64 q[4][E / QC];
 #pragma unroll
-                for (int r = 0; r < E / 4; r++) {
-                    const u32 j = tid + ((u32)(h * (E / 4) + r) << LOGT);
+                for (int r = 0; r < E / QC; r++) {
+                    const u32 j = tid + ((u32)(h * (E / QC) + r) << LOGT);
 #pragma unroll
                     for (int k = 0; k < 4; k++) q[k][r] = s[j + ((u32)k << LOGB)];
                 }
                 TFHE_SCHED_FENCE();
 #pragma unroll
-                for (int r = 0; r < E / 4; r++) {
+                for (int r = 0; r < E / QC; r++) {
                     const double x0 = fp_from_u64(q[0][r]), x1 = fp_from_u64(q[1][r]);
                     const double t2 = fp_mulmod_c(fp_from_u64(q[2][r]), w1, C.p, C.pinv);
                     const double t3 = fp_mulmod_c(fp_from_u64(q[3][r]), w1, C.p, C.pinv);
                     // |y| <= 1.92 p, products <= 1.31 p (fp64arith.h); the sub-blocks take reduced operands
                     const double u0 = fp_mulmod_c(x1 + t3, w2, C.p, C.pinv), u1 = fp_mulmod_c(x1 - t3, w3, C.p, C.pinv);
-                    w[0][h * (E / 4) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u0, x0 + t2), C.p, C.pinv));
-                    w[1][h * (E / 4) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u1, x0 - t2), C.p, C.pinv));
+                    w[0][h * (E / QC) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u0, x0 + t2), C.p, C.pinv));
+                    w[1][h * (E / QC) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u1, x0 - t2), C.p, C.pinv));
                 }
                 TFHE_SCHED_FENCE();
             }
@@ -721,31 +722,33 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
             __syncthreads();
             ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
             __syncthreads();
-            {
+            static_assert(G3::SETS == 2, "last pass: two register sets");
+            // one register set at a time: halves the transient next to the 64 held / waiting registers
+            auto last_set = [&](auto uc) {
+                constexpr int U = decltype(uc)::value;
                 u64 r3[E];
                 typename A::elem v[E];
-                fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
-                fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, pre);
+                fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true, U>(r3, lds, nullptr, tid);
+                fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0, U>(v, r3, nullptr, C, tid, pre);
+                u32 c0, hi, base;
+                G3::template coords<true>(tid, U, c0, hi, base);
 #pragma unroll
-                for (int u = 0; u < G3::SETS; u++) {
-                    u32 c0, hi, base;
-                    G3::template coords<true>(tid, u, c0, hi, base);
-#pragma unroll
-                    for (int r = 0; r < G3::R; r++) {
-                        const int e = u * G3::R + r;
-                        const u64 o = A::out_fwd(v[e], C);
-                        if (half == 0) {
-                            held[e] = o;
-                        } else {
-                            const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
-                            u64x2_t ww;
-                            ww.x = held[e];
-                            ww.y = o;
-                            *(u64x2_t*)(d + ((u64)nat << x)) = ww;
-                        }
+                for (int r = 0; r < G3::R; r++) {
+                    const int e = U * G3::R + r;
+                    const u64 o = A::out_fwd(v[e], C);
+                    if (half == 0) {
+                        held[e] = o;
+                    } else {
+                        const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
+                        u64x2_t ww;
+                        ww.x = held[e];
+                        ww.y = o;
+                        *(u64x2_t*)(d + ((u64)nat << x)) = ww;
                     }
                 }
-            }
+            };
+            last_set(std::integral_constant<int, 0>());
+            last_set(std::integral_constant<int, 1>());
         }
     }
 }
