@@ -480,9 +480,12 @@ __global__ __launch_bounds__(1 << LOGT, IOMODE == 2 ? 2 : TFHE_NTT_WAVES) void k
 //            (position 2 nat + sb).
 //   inverse: sub-block sb reads words 2 nat + sb; out_lo = (r0 + r1) N^-1, out_hi = (r0 - r1) W[1]^-1 N^-1.
 // ------------------------------------------------------------------------------------------------
-template <class A, int LOGB, int LOGT>
+// LIFT: the rows are key-switch digits (ntt_io_t mode 1): item (b, i, j) reads limb i of c[end] of ciphertext b and lifts
+// it, centred, into working limb j while loading (rlwe_she.jl:326-329) -- the digit rows are never stored untransformed.
+template <class A, int LOGB, int LOGT, bool LIFT = false>
 __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems) {
+                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems,
+                                                             ntt_io_t io) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
     static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass schedule expected");
@@ -491,8 +494,18 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
     const u32 tid = threadIdx.x;
     bool first = true;
     for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const typename A::ctx C = A::make(LT[sel.idx[item % (u32)sel.n]]);
-        const u64* s = src + ((size_t)item << (LOGB + 1));
+        u32 srow = item, j = item % (u32)sel.n;
+        lift_t lf;
+        if constexpr (LIFT) {
+            const u32 per_ct = io.level * io.nw, b = item / per_ct, rem = item % per_ct, i = rem / io.nw;
+            j = rem % io.nw;
+            srow = (b * io.polys + io.polys - 1) * io.level + i;
+            const ntt_limb_t& Li = LT[sel.idx[i]];
+            const ntt_limb_t& Lj = LT[sel.idx[j]];
+            lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
+        }
+        const typename A::ctx C = A::make(LT[sel.idx[j]]);
+        const u64* s = src + ((size_t)srow << (LOGB + 1));
         u64* d = dst + ((size_t)item << (LOGB + 1));
         u64 wa[E], wb[E];  // the two sub-blocks' first-pass operands (element bits)
         {
@@ -501,9 +514,11 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
             for (int h = 0; h < 2; h++) {  // two halves: bounds the raw operands in flight next to the 128 result registers
 #pragma unroll
                 for (int r = h * (E / 2); r < (h + 1) * (E / 2); r++) {
-                    const u32 j = tid + ((u32)r << LOGT);
-                    const double lo = fp_from_u64(s[j]);
-                    const double t = fp_mulmod_c(fp_from_u64(s[j + (1u << LOGB)]), w1, C.p, C.pinv);
+                    const u32 k = tid + ((u32)r << LOGT);
+                    // lifted digits enter loosely (|v| <= p, ArithFp::from_global_lift): lo + t <= 1.92 p before the reduction
+                    const double lo = LIFT ? A::from_global_lift(s[k], C, lf, true) : fp_from_u64(s[k]);
+                    const double hv = LIFT ? A::from_global_lift(s[k + (1u << LOGB)], C, lf, true) : fp_from_u64(s[k + (1u << LOGB)]);
+                    const double t = fp_mulmod_c(hv, w1, C.p, C.pinv);
                     wa[r] = A::to_lds(fp_reduce(lo + t, C.p, C.pinv));
                     wb[r] = A::to_lds(fp_reduce(lo - t, C.p, C.pinv));
                 }

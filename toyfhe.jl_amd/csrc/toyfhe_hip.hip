@@ -282,15 +282,17 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
         }
     }
     // N > 2^14: x top stages on global memory + 2^14 blocks; needs an out-of-place intermediate
-    if (iop) return fail(TFHE_E_UNSUPPORTED, "fused NTT I/O transforms need N <= 2^14");
     const int x = n - 14;
-    if (x == 1 && c->variant == 0 && sel_fp(c, sel, 1)) {
+    const bool pair15 = x == 1 && c->variant == 0 && sel_fp(c, sel, 1);
+    if (iop && !(pair15 && !inverse && io.mode == 1)) return fail(TFHE_E_UNSUPPORTED, "fused NTT I/O transforms need N <= 2^14 (digit lift: N = 2^15, fp64 policy)");
+    if (pair15) {
         // N = 2^15, fp64 policy: top stage and both 2^14 sub-blocks in one kernel (one read + one write of the row)
         constexpr int LOGT = logt_for(14);
         const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
         static bool pattr_set = false;
         if (!pattr_set) {
             int rc2 = set_lds(k_ntt_fwd_pair<ArithFp, 14, LOGT>, lds);
+            if (!rc2) rc2 = set_lds(k_ntt_fwd_pair<ArithFp, 14, LOGT, true>, lds);
             if (!rc2) rc2 = set_lds(k_ntt_inv_pair<ArithFp, 14, LOGT>, lds);
             if (rc2) return rc2;
             pattr_set = true;
@@ -298,7 +300,8 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
         const unsigned grid = std::min((unsigned)rows, (unsigned)c->num_cus);
         prof_begin(c, rows);
         if (inverse) hipLaunchKernelGGL((k_ntt_inv_pair<ArithFp, 14, LOGT>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows);
-        else hipLaunchKernelGGL((k_ntt_fwd_pair<ArithFp, 14, LOGT>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows);
+        else if (io.mode == 1) hipLaunchKernelGGL((k_ntt_fwd_pair<ArithFp, 14, LOGT, true>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows, io);
+        else hipLaunchKernelGGL((k_ntt_fwd_pair<ArithFp, 14, LOGT>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows, io);
         prof_end(c);
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
@@ -668,7 +671,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
-    if (c->logN <= 14) {
+    if (c->logN <= 14 || (c->logN == 15 && c->variant == 0 && sel_fp(c, A.w, 1))) {
         // digits: centred lift of limb i of c[end] into every working limb, fused into the forward NTT's loads
         ntt_io_t io = io_plain();
         io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys;
