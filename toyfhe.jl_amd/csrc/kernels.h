@@ -674,9 +674,11 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_subpair(const u64* __rest
 // per point instead of the 2 a full radix-4 would spend on them) and runs them as in k_ntt_fwd_subpair.  The row's other
 // workgroup (same XCD, same iteration: xcd_walk_item) reads the same lines from L2 -- one HBM read and one write of the
 // row instead of two of each with k_ntt_fwd_top in front.
-template <class A, int LOGB, int LOGT>
+// LIFT: key-switch digit rows (ntt_io_t mode 1), lifted while loading as in k_ntt_fwd_pair.
+template <class A, int LOGB, int LOGT, bool LIFT = false>
 __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems) {
+                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems,
+                                                             ntt_io_t io) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     constexpr int x = 2;
     constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
@@ -690,8 +692,18 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
         const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x - 1, nitems);
         if (item == ~0u) continue;
         const u32 ph = item & 1u, pl = item >> 1;
-        const typename A::ctx C = A::make(LT[sel.idx[pl % (u32)sel.n]]);
-        const u64* s = src + pl * ntot;
+        u32 srow = pl, j = pl % (u32)sel.n;
+        lift_t lf;
+        if constexpr (LIFT) {
+            const u32 per_ct = io.level * io.nw, b = pl / per_ct, rem = pl % per_ct, i = rem / io.nw;
+            j = rem % io.nw;
+            srow = (b * io.polys + io.polys - 1) * io.level + i;
+            const ntt_limb_t& Li = LT[sel.idx[i]];
+            const ntt_limb_t& Lj = LT[sel.idx[j]];
+            lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
+        }
+        const typename A::ctx C = A::make(LT[sel.idx[j]]);
+        const u64* s = src + srow * ntot;
         u64* d = dst + pl * ntot + brev_bits(ph, x);
         u64 w[2][E];  // the two sub-blocks' first-pass operands (element bits)
         {
@@ -711,9 +723,12 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
                 TFHE_SCHED_FENCE();
 #pragma unroll
                 for (int r = 0; r < E / QC; r++) {
-                    const double x0 = fp_from_u64(q[0][r]), x1 = fp_from_u64(q[1][r]);
-                    const double t2 = fp_mulmod_c(fp_from_u64(q[2][r]), w1, C.p, C.pinv);
-                    const double t3 = fp_mulmod_c(fp_from_u64(q[3][r]), w1, C.p, C.pinv);
+                    double xin[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) xin[k] = LIFT ? A::from_global_lift(q[k][r], C, lf, true) : fp_from_u64(q[k][r]);
+                    const double x0 = xin[0], x1 = xin[1];
+                    const double t2 = fp_mulmod_c(xin[2], w1, C.p, C.pinv);
+                    const double t3 = fp_mulmod_c(xin[3], w1, C.p, C.pinv);
                     // |y| <= 1.92 p, products <= 1.31 p (fp64arith.h); the sub-blocks take reduced operands
                     const double u0 = fp_mulmod_c(x1 + t3, w2, C.p, C.pinv), u1 = fp_mulmod_c(x1 - t3, w3, C.p, C.pinv);
                     w[0][h * (E / QC) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u0, x0 + t2), C.p, C.pinv));

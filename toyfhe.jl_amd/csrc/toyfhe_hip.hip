@@ -284,7 +284,8 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
     // N > 2^14: x top stages on global memory + 2^14 blocks; needs an out-of-place intermediate
     const int x = n - 14;
     const bool pair15 = x == 1 && c->variant == 0 && sel_fp(c, sel, 1);
-    if (iop && !(pair15 && !inverse && io.mode == 1)) return fail(TFHE_E_UNSUPPORTED, "fused NTT I/O transforms need N <= 2^14 (digit lift: N = 2^15, fp64 policy)");
+    if (iop && x == 1 && !(pair15 && !inverse && io.mode == 1))
+        return fail(TFHE_E_UNSUPPORTED, "fused NTT I/O transforms need N <= 2^14 (digit lift: N <= 2^16, fp64 policy)");
     if (pair15) {
         // N = 2^15, fp64 policy: top stage and both 2^14 sub-blocks in one kernel (one read + one write of the row)
         constexpr int LOGT = logt_for(14);
@@ -309,18 +310,25 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
     if (x > 3) return fail(TFHE_E_UNSUPPORTED, "N = 2^%d not supported (max 2^17)", n);
     // fp64 policy: two sub-blocks per workgroup (16-byte pieces on the natural-order side)
     const bool pairable = x >= 2 && c->variant == 0 && sel_fp(c, sel, x) && (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0;
+    if (iop && !(pairable && x == 2 && !inverse && io.mode == 1 && src != dst))
+        return fail(TFHE_E_UNSUPPORTED, "fused NTT I/O transforms need N <= 2^14 (digit lift: N <= 2^16, fp64 policy)");
     if (!inverse && pairable && x == 2 && src != dst) {
         // N = 2^16 forward in one kernel: top stages folded into the paired sub-block kernel (out of place only: the
         // row's other workgroup reads the same source words)
         constexpr int LOGT = logt_for(14);
         const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
-        auto qk = k_ntt_fwd_quad<ArithFp, 14, LOGT>;
+        auto qk = io.mode == 1 ? k_ntt_fwd_quad<ArithFp, 14, LOGT, true> : k_ntt_fwd_quad<ArithFp, 14, LOGT, false>;
         static bool qattr_set = false;
-        if (!qattr_set) { int rc2 = set_lds(qk, lds); if (rc2) return rc2; qattr_set = true; }
+        if (!qattr_set) {
+            int rc2 = set_lds(k_ntt_fwd_quad<ArithFp, 14, LOGT, true>, lds);
+            if (!rc2) rc2 = set_lds(k_ntt_fwd_quad<ArithFp, 14, LOGT, false>, lds);
+            if (rc2) return rc2;
+            qattr_set = true;
+        }
         const unsigned items = (unsigned)(rows << 1);
         const unsigned grid = std::min(items, (unsigned)c->num_cus);
         prof_begin(c, rows);
-        hipLaunchKernelGGL(qk, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, items);
+        hipLaunchKernelGGL(qk, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, items, io);
         prof_end(c);
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
@@ -671,7 +679,9 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
-    if (c->logN <= 14 || (c->logN == 15 && c->variant == 0 && sel_fp(c, A.w, 1))) {
+    const bool lift_fused = c->logN <= 14 || ((c->logN == 15 || c->logN == 16) && c->variant == 0 && sel_fp(c, A.w, c->logN - 14) &&
+                                              (((uintptr_t)ct | (uintptr_t)dig) & 15u) == 0);
+    if (lift_fused) {
         // digits: centred lift of limb i of c[end] into every working limb, fused into the forward NTT's loads
         ntt_io_t io = io_plain();
         io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys;
