@@ -1284,6 +1284,129 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same for N = 2^(LOGB+1): one (ciphertext b, working limb j, sub-block sb) per workgroup pass.  In the transform
+// domain the key product is pointwise, so each of the two 2^LOGB sub-blocks of the 2^(LOGB+1)-point transform can be
+// carried on its own: the workgroup forms its sub-block's operands from the two halves of the lifted source row (top
+// stage: lo +- W[1] hi, as k_ntt_fwd_pair), runs the sub-block's forward passes, multiplies by the key words at the
+// natural-order positions 2 nat + sb and accumulates in registers; the two accumulators then go through the sub-block's
+// inverse passes and are written, canonical, to T [batch][2][nw][2][2^LOGB].  The inverse top stage (which needs both
+// sub-blocks) is k_ntt_inv_top<1> over T, followed by the usual tail (k_ks_add_ct / k_ks_rescale_add).  The digit rows
+// and their transforms never reach HBM; the two sub-block items of a (b, j) run on one XCD (xcd_walk_item) and share
+// the source rows in its L2.
+// ------------------------------------------------------------------------------------------------
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restrict__ evk, const u64* __restrict__ ct,
+                                                             u64* __restrict__ T, const ntt_limb_t* __restrict__ LT,
+                                                             ks_arg_t KA, int Lk, u32 nitems) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
+    static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass forward schedule expected");
+    constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB), S1 = LOGB - KI1;
+    static_assert(KI1 == K3, "forward last pass and inverse first pass must share the register map");
+    typedef pgeom<LOGB, LOGT, K1 + K2, K3> G3;
+    constexpr int E = G3::E;
+    const u32 level = (u32)KA.level, polys = (u32)KA.polys, nw = (u32)KA.nw;
+    const u32 niter = (nitems + gridDim.x - 1) / gridDim.x;
+    bool first = true;
+    for (u32 it = 0; it < niter; it++) {
+        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, 1, nitems);
+        if (item == ~0u) continue;
+        const u32 sb = item & 1u, pl = item >> 1, b = pl / nw, j = pl % nw, pre = 2u + sb;
+        const ntt_limb_t& Lj = LT[KA.w.idx[j]];
+        const typename A::ctx C = A::make(Lj);
+        lift_t lf;
+        lf.qj = Lj.q;
+        lf.bj = Lj.br;
+        const typename A::tw w1 = A::ld_fwd(C, 1u);
+        const double sgn = sb ? -1.0 : 1.0;
+        typename A::elem acc[2][E];
+#pragma unroll
+        for (int e = 0; e < E; e++) acc[0][e] = acc[1][e] = 0;
+        for (u32 i = 0; i < level; i++) {
+            const u32 tid = fresh_tid();
+            lf.qi = LT[KA.w.idx[i]].q;
+            lf.half = lf.qi >> 1;
+            const u64* grow = ct + ((size_t)((b * polys + polys - 1) * level + i) << (LOGB + 1));
+            typename A::elem v[E];
+            {
+                u64 op[E];  // first-pass operands of this sub-block (element bits)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    u64 q0[E / 2], q1[E / 2];
+#pragma unroll
+                    for (int r = 0; r < E / 2; r++) {
+                        const u32 k = tid + ((u32)(h * (E / 2) + r) << LOGT);
+                        q0[r] = grow[k];
+                        q1[r] = grow[k + (1u << LOGB)];
+                    }
+                    TFHE_SCHED_FENCE();
+#pragma unroll
+                    for (int r = 0; r < E / 2; r++) {
+                        // loosely lifted digits (|v| <= p): lo +- t <= 1.92 p before the reduction
+                        const double lo = A::from_global_lift(q0[r], C, lf, true);
+                        const double t = fp_mulmod_c(A::from_global_lift(q1[r], C, lf, true), w1, C.p, C.pinv);
+                        op[h * (E / 2) + r] = A::to_lds(fp_reduce(fp_fma(sgn, t, lo), C.p, C.pinv));
+                    }
+                    TFHE_SCHED_FENCE();
+                }
+                if (!first) __syncthreads();  // the previous transform's last pass has read LDS
+                first = false;
+                fwd_compute<A, LOGB, LOGT, 0, K1, false, false, 0>(v, op, nullptr, C, tid, pre);
+                fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+            }
+            __syncthreads();
+            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            __syncthreads();
+            {
+                u64 r3[E];
+                fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
+                fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, pre);
+            }
+            // multiply-accumulate with the key words at natural-order positions 2 nat + sb
+            const u64* e_mask = evk + (((size_t)i * 2 + 0) * Lk + KA.w.idx[j] << (LOGB + 1)) + sb;
+            const u64* e_masked = evk + (((size_t)i * 2 + 1) * Lk + KA.w.idx[j] << (LOGB + 1)) + sb;
+#pragma unroll
+            for (int u = 0; u < G3::SETS; u++) {
+                u32 c0, hi, base;
+                G3::template coords<true>(tid, u, c0, hi, base);
+#pragma unroll
+                for (int r = 0; r < G3::R; r++) {
+                    const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
+                    const int e = u * G3::R + r;
+                    const typename A::tw k1{fp_from_u64(e_masked[2u * nat])}, k0{fp_from_u64(e_mask[2u * nat])};
+                    const double y = fp_reduce(v[e], C.p, C.pinv);  // range: as k_ks_fused
+                    acc[0][e] += fp_mulmod_c(y, k1, C.p, C.pinv);
+                    acc[1][e] += fp_mulmod_c(y, k0, C.p, C.pinv);
+                }
+            }
+            if ((i & 7u) == 7u && i + 1 < level) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    acc[0][e] = fp_reduce(acc[0][e], C.p, C.pinv);
+                    acc[1][e] = fp_reduce(acc[1][e], C.p, C.pinv);
+                }
+            }
+        }
+        // the sub-block's inverse passes on the two accumulators (first pass from registers: same natural-order map)
+#pragma unroll
+        for (int sidx = 0; sidx < 2; sidx++) {
+            const u32 tid = fresh_tid();
+            u64* gdst = T + ((size_t)((b * 2 + sidx) * nw + j) << (LOGB + 1)) + ((size_t)sb << LOGB);
+            __syncthreads();  // the previous transform's last pass has read LDS
+            {
+                typename A::elem* v = acc[sidx];
+#pragma unroll
+                for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], C.p, C.pinv);
+                inv_compute<A, LOGB, LOGT, S1, KI1, true, false, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, pre);
+                inv_store<A, LOGB, LOGT, S1, KI1, true, false>(v, lds, nullptr, C, tid);
+            }
+            __syncthreads();
+            inv_schedule<A, LOGB, LOGT, S1, false>(lds, nullptr, gdst, C, tid, pre, 0, 0u, nullptr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The inside of a BFV multiplication for one (ciphertext b, limb j of ℛbig) per workgroup pass, fp64 policy, whole-
 // transform blocks:   T_k[b][j] = INTT_j( tensor_k( NTT_j(a0), NTT_j(a1), NTT_j(b0), NTT_j(b1) ) ),  k = 0, 1, 2
 // (enc_mul, rlwe_she.jl:255-258, between mul_expand and mul_contract).  The four forward transforms, the tensor product

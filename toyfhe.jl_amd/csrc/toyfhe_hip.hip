@@ -679,6 +679,35 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
+    if (c->logN == 15 && c->variant == 0 && sel_fp(c, A.w, 1) && level >= 2) {
+        // N = 2^15: per-sub-block fused key switch (k_ks_fused_sub) into T = dig ([batch][2][nw] rows, level >= 2 makes room),
+        // then the inverse top stage over T and the usual tail
+        constexpr int LOGT = logt_for(14);
+        const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
+        auto fk = k_ks_fused_sub<ArithFp, 14, LOGT>;
+        static bool sattr_set = false;
+        if (!sattr_set) { rc = set_lds(fk, lds); if (rc) return rc; sattr_set = true; }
+        const unsigned items = (unsigned)(batch * nw * 2);
+        const unsigned grid = std::min(items, (unsigned)c->num_cus);
+        prof_begin(c, (int64_t)batch * nw * (level + 2));
+        hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evk, ct, dig, c->limbs_dev, A, Lk, items);
+        prof_end(c);
+        HIP_TRY(hipGetLastError());
+        const dim3 tg((unsigned)((((n >> 1) + 255) / 256) * (batch * 2 * nw)));
+        hipLaunchKernelGGL(k_ntt_inv_top<1>, tg, dim3(256), 0, c->stream, dig, special ? S : out, c->limbs_dev, A.w, c->logN);
+        HIP_TRY(hipGetLastError());
+        if (special) {
+            rescale_arg_t ra;
+            memset(&ra, 0, sizeof ra);
+            const u64 P = c->q[Lk - 1];
+            for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+            hipLaunchKernelGGL(k_ks_rescale_add, dim3((unsigned)(batch * 2 * level)), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
+        } else {
+            hipLaunchKernelGGL(k_ks_add_ct, dim3((unsigned)(batch * 2 * level)), dim3(256), 0, c->stream, ct, out, c->limbs_dev, A, n, add_s);
+        }
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
     const bool lift_fused = c->logN <= 14 || ((c->logN == 15 || c->logN == 16) && c->variant == 0 && sel_fp(c, A.w, c->logN - 14) &&
                                               (((uintptr_t)ct | (uintptr_t)dig) & 15u) == 0);
     if (lift_fused) {
