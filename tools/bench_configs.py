@@ -3,7 +3,7 @@
 operation on synthetic residues, 1 GPU.
   cfg#3  CKKS  N=2^15, 10 limbs @40 bit + special prime: rotate (galois + key switch), rescale
   cfg#4        N=2^14,  6 limbs @50 bit + special prime: key switch only
-  cfg#5        N=2^16,  7 limbs @50 bit: forward / inverse NTT
+  cfg#5        N=2^16,  6 limbs @50 bit + special prime: key switch / rotate; 7 limbs: forward / inverse NTT
 usage: bench_configs.py [batch]"""
 import sys, os, time
 import numpy as np
@@ -40,6 +40,7 @@ def keyswitch_case(name, logn, bits, level, b):
 
 keyswitch_case("cfg#3", 15, 40, 10, batch)
 keyswitch_case("cfg#4", 14, 50, 6, batch * 4)
+keyswitch_case("cfg#5", 16, 50, 6, max(8, batch // 2))
 N = 1 << 16
 ctx = tf.Context(N, H.chain(50, 7, N))
 rows = 7 * max(8, batch // 4)

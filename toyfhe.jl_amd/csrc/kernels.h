@@ -140,6 +140,10 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_block(con
 }
 template <class T>
 __device__ __forceinline__ void pin_vgpr(T& x) { asm volatile("" : "+v"(x)); }
+// make `idx` (an address component of later loads) depend on `v`: loads through read-only __restrict__ pointers are
+// invariant to the compiler and float above TFHE_SCHED_FENCE, so a piece-wise load phase needs a data dependence to keep
+// piece h+1's requests behind piece h's arithmetic (otherwise every piece is requested at once and spilled)
+__device__ __forceinline__ void order_after(u32& idx, u64 v) { asm volatile("" : "+v"(idx) : "v"(v)); }
 #define TFHE_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // Register-prefetch variant of the forward block kernel (whole rows, plain I/O): the operands of item i+1 are loaded
 // into registers underneath the MIDDLE pass of item i, one load per few butterflies during its first half
@@ -1284,17 +1288,17 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same for N = 2^(LOGB+1): one (ciphertext b, working limb j, sub-block sb) per workgroup pass.  In the transform
-// domain the key product is pointwise, so each of the two 2^LOGB sub-blocks of the 2^(LOGB+1)-point transform can be
-// carried on its own: the workgroup forms its sub-block's operands from the two halves of the lifted source row (top
-// stage: lo +- W[1] hi, as k_ntt_fwd_pair), runs the sub-block's forward passes, multiplies by the key words at the
-// natural-order positions 2 nat + sb and accumulates in registers; the two accumulators then go through the sub-block's
-// inverse passes and are written, canonical, to T [batch][2][nw][2][2^LOGB].  The inverse top stage (which needs both
-// sub-blocks) is k_ntt_inv_top<1> over T, followed by the usual tail (k_ks_add_ct / k_ks_rescale_add).  The digit rows
-// and their transforms never reach HBM; the two sub-block items of a (b, j) run on one XCD (xcd_walk_item) and share
-// the source rows in its L2.
+// The same for N = 2^(LOGB+X), X = 1, 2: one (ciphertext b, working limb j, sub-block sb) per workgroup pass.  In the
+// transform domain the key product is pointwise, so each of the 2^X sub-blocks of the transform can be carried on its
+// own: the workgroup forms its sub-block's operands from the 2^X parts of the lifted source row (its one output of the
+// top stages, as k_ntt_fwd_pair / k_ntt_fwd_quad), runs the sub-block's forward passes, multiplies by the key words at
+// the natural-order positions (nat << X) + brv_X(sb) and accumulates in registers; the two accumulators then go through
+// the sub-block's inverse passes and are written, canonical, to T [batch][2][nw][2^X][2^LOGB].  The inverse top stages
+// (which need all sub-blocks) are k_ntt_inv_top<X> over T, followed by the usual tail (k_ks_add_ct / k_ks_rescale_add).
+// The digit rows and their transforms never reach HBM; the sub-block items of a (b, j) run on one XCD (xcd_walk_item)
+// and share the source rows in its L2.
 // ------------------------------------------------------------------------------------------------
-template <class A, int LOGB, int LOGT>
+template <class A, int LOGB, int LOGT, int X>
 __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restrict__ evk, const u64* __restrict__ ct,
                                                              u64* __restrict__ T, const ntt_limb_t* __restrict__ LT,
                                                              ks_arg_t KA, int Lk, u32 nitems) {
@@ -1309,16 +1313,17 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
     const u32 niter = (nitems + gridDim.x - 1) / gridDim.x;
     bool first = true;
     for (u32 it = 0; it < niter; it++) {
-        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, 1, nitems);
+        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, X, nitems);
         if (item == ~0u) continue;
-        const u32 sb = item & 1u, pl = item >> 1, b = pl / nw, j = pl % nw, pre = 2u + sb;
+        const u32 sb = item & ((1u << X) - 1u), pl = item >> X, b = pl / nw, j = pl % nw, pre = (1u << X) + sb;
         const ntt_limb_t& Lj = LT[KA.w.idx[j]];
         const typename A::ctx C = A::make(Lj);
         lift_t lf;
         lf.qj = Lj.q;
         lf.bj = Lj.br;
-        const typename A::tw w1 = A::ld_fwd(C, 1u);
-        const double sgn = sb ? -1.0 : 1.0;
+        // top stages: sub-block sb = (h, q) takes x0 +- W[1] x1 (X = 1), or (x0 +- W[1] x2) +- W[2+h] (x1 +- W[1] x3) (X = 2)
+        const typename A::tw w1 = A::ld_fwd(C, 1u), w2 = A::ld_fwd(C, 2u + (sb >> 1));
+        const double sgn_h = (sb >> (X - 1)) ? -1.0 : 1.0, sgn_q = (sb & 1u) ? -1.0 : 1.0;
         typename A::elem acc[2][E];
 #pragma unroll
         for (int e = 0; e < E; e++) acc[0][e] = acc[1][e] = 0;
@@ -1326,26 +1331,38 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
             const u32 tid = fresh_tid();
             lf.qi = LT[KA.w.idx[i]].q;
             lf.half = lf.qi >> 1;
-            const u64* grow = ct + ((size_t)((b * polys + polys - 1) * level + i) << (LOGB + 1));
+            const u64* grow = ct + ((size_t)((b * polys + polys - 1) * level + i) << (LOGB + X));
             typename A::elem v[E];
             {
                 u64 op[E];  // first-pass operands of this sub-block (element bits)
+                constexpr int PC = 4 * X, PE = E / PC;  // pieces of the load phase (bounds the raw words in flight)
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    u64 q0[E / 2], q1[E / 2];
+                for (int h = 0; h < PC; h++) {
+                    u64 q[1 << X][PE];
+                    u32 tp = tid;
+                    if (h > 0) order_after(tp, op[h * PE - 1]);
 #pragma unroll
-                    for (int r = 0; r < E / 2; r++) {
-                        const u32 k = tid + ((u32)(h * (E / 2) + r) << LOGT);
-                        q0[r] = grow[k];
-                        q1[r] = grow[k + (1u << LOGB)];
+                    for (int r = 0; r < PE; r++) {
+                        const u32 k = tp + ((u32)(h * PE + r) << LOGT);
+#pragma unroll
+                        for (int m = 0; m < (1 << X); m++) q[m][r] = grow[k + ((u32)m << LOGB)];
                     }
                     TFHE_SCHED_FENCE();
 #pragma unroll
-                    for (int r = 0; r < E / 2; r++) {
-                        // loosely lifted digits (|v| <= p): lo +- t <= 1.92 p before the reduction
-                        const double lo = A::from_global_lift(q0[r], C, lf, true);
-                        const double t = fp_mulmod_c(A::from_global_lift(q1[r], C, lf, true), w1, C.p, C.pinv);
-                        op[h * (E / 2) + r] = A::to_lds(fp_reduce(fp_fma(sgn, t, lo), C.p, C.pinv));
+                    for (int r = 0; r < PE; r++) {
+                        // loosely lifted digits (|v| <= p): sums <= 1.92 p, products <= 1.31 p, <= 3.23 p before the reduction
+                        double xin[1 << X];
+#pragma unroll
+                        for (int m = 0; m < (1 << X); m++) xin[m] = A::from_global_lift(q[m][r], C, lf, true);
+                        double z;
+                        if constexpr (X == 1) {
+                            z = fp_fma(sgn_h, fp_mulmod_c(xin[1], w1, C.p, C.pinv), xin[0]);
+                        } else {
+                            const double ya = fp_fma(sgn_h, fp_mulmod_c(xin[2], w1, C.p, C.pinv), xin[0]);
+                            const double yb = fp_fma(sgn_h, fp_mulmod_c(xin[3], w1, C.p, C.pinv), xin[1]);
+                            z = fp_fma(sgn_q, fp_mulmod_c(yb, w2, C.p, C.pinv), ya);
+                        }
+                        op[h * PE + r] = A::to_lds(fp_reduce(z, C.p, C.pinv));
                     }
                     TFHE_SCHED_FENCE();
                 }
@@ -1363,8 +1380,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, pre);
             }
             // multiply-accumulate with the key words at natural-order positions 2 nat + sb
-            const u64* e_mask = evk + (((size_t)i * 2 + 0) * Lk + KA.w.idx[j] << (LOGB + 1)) + sb;
-            const u64* e_masked = evk + (((size_t)i * 2 + 1) * Lk + KA.w.idx[j] << (LOGB + 1)) + sb;
+            const u64* e_mask = evk + (((size_t)i * 2 + 0) * Lk + KA.w.idx[j] << (LOGB + X)) + brev_bits(sb, X);
+            const u64* e_masked = evk + (((size_t)i * 2 + 1) * Lk + KA.w.idx[j] << (LOGB + X)) + brev_bits(sb, X);
 #pragma unroll
             for (int u = 0; u < G3::SETS; u++) {
                 u32 c0, hi, base;
@@ -1373,7 +1390,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 for (int r = 0; r < G3::R; r++) {
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
                     const int e = u * G3::R + r;
-                    const typename A::tw k1{fp_from_u64(e_masked[2u * nat])}, k0{fp_from_u64(e_mask[2u * nat])};
+                    const typename A::tw k1{fp_from_u64(e_masked[nat << X])}, k0{fp_from_u64(e_mask[nat << X])};
                     const double y = fp_reduce(v[e], C.p, C.pinv);  // range: as k_ks_fused
                     acc[0][e] += fp_mulmod_c(y, k1, C.p, C.pinv);
                     acc[1][e] += fp_mulmod_c(y, k0, C.p, C.pinv);
@@ -1391,7 +1408,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
 #pragma unroll
         for (int sidx = 0; sidx < 2; sidx++) {
             const u32 tid = fresh_tid();
-            u64* gdst = T + ((size_t)((b * 2 + sidx) * nw + j) << (LOGB + 1)) + ((size_t)sb << LOGB);
+            u64* gdst = T + ((size_t)((b * 2 + sidx) * nw + j) << (LOGB + X)) + ((size_t)sb << LOGB);
             __syncthreads();  // the previous transform's last pass has read LDS
             {
                 typename A::elem* v = acc[sidx];

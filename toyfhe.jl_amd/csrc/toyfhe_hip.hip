@@ -680,20 +680,22 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         return TFHE_OK;
     }
     if (c->logN == 15 && c->variant == 0 && sel_fp(c, A.w, 1) && level >= 2) {
-        // N = 2^15: per-sub-block fused key switch (k_ks_fused_sub) into T = dig ([batch][2][nw] rows, level >= 2 makes room),
-        // then the inverse top stage over T and the usual tail
+        // N = 2^15: per-sub-block fused key switch (k_ks_fused_sub) into T = dig ([batch][2][nw] rows, level >= 2 makes
+        // room), then the inverse top stage over T and the usual tail.  (The X = 2 instance for N = 2^16 measured slower
+        // than the three-kernel path below: 235 spilled registers next to the 128 accumulator registers.)
         constexpr int LOGT = logt_for(14);
         const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
-        auto fk = k_ks_fused_sub<ArithFp, 14, LOGT>;
+        const int x = 1;
+        auto fk = k_ks_fused_sub<ArithFp, 14, LOGT, 1>;
         static bool sattr_set = false;
         if (!sattr_set) { rc = set_lds(fk, lds); if (rc) return rc; sattr_set = true; }
-        const unsigned items = (unsigned)(batch * nw * 2);
+        const unsigned items = (unsigned)((batch * nw) << x);
         const unsigned grid = std::min(items, (unsigned)c->num_cus);
         prof_begin(c, (int64_t)batch * nw * (level + 2));
         hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evk, ct, dig, c->limbs_dev, A, Lk, items);
         prof_end(c);
         HIP_TRY(hipGetLastError());
-        const dim3 tg((unsigned)((((n >> 1) + 255) / 256) * (batch * 2 * nw)));
+        const dim3 tg((unsigned)((((n >> x) + 255) / 256) * (batch * 2 * nw)));
         hipLaunchKernelGGL(k_ntt_inv_top<1>, tg, dim3(256), 0, c->stream, dig, special ? S : out, c->limbs_dev, A.w, c->logN);
         HIP_TRY(hipGetLastError());
         if (special) {
