@@ -1599,29 +1599,19 @@ __global__ __launch_bounds__(BFV_BS) void k_bfv_contract(const u64* __restrict__
 // input ciphertexts
 template <int NS, int NP>
 __global__ __launch_bounds__(256) void k_bfv_expand_fast(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                          const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx, int copy_shared,
-                                                          u32 reps) {
-    const u32 k0 = (blockIdx.x % gx) * 256 + threadIdx.x;
+                                                          const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx, int copy_shared) {
+    const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
     const size_t p = blockIdx.x / gx;
-    const u32 span = n / reps;
-    if (k0 >= span) return;
-    for (u32 r = 0; r < reps; r++) {
-        const u32 k = k0 + r * span;
-        if (Bt->narrow) bfv_expand_narrow<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
-        else bfv_expand_fast<NS, NP, false>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
-    }
+    if (k >= n) return;
+    if (Bt->narrow) bfv_expand_narrow<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
+    else bfv_expand_fast<NS, NP, false>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
 }
 template <int NS, int NP>
 __global__ __launch_bounds__(256) void k_bfv_contract_fast(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                            const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx, u32 reps) {
-    // `reps` coefficients per thread (stride n/reps): the per-wave scalar loads of the conversion constants are shared
-    const u32 k0 = (blockIdx.x % gx) * 256 + threadIdx.x;
+                                                            const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx) {
+    const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
     const size_t p = blockIdx.x / gx;
-    const u32 span = n / reps;
-    if (k0 >= span) return;
-    for (u32 r = 0; r < reps; r++) {
-        const u32 k = k0 + r * span;
-        if (Bt->narrow) bfv_contract_narrow<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
-        else bfv_contract_fast<NS, NP, false>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
-    }
+    if (k >= n) return;
+    if (Bt->narrow) bfv_contract_narrow<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
+    else bfv_contract_fast<NS, NP, false>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
 }
