@@ -26,8 +26,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="ciphertext pairs per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="ciphertexts per internal pipeline chunk (0 = default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
