@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void k_pointwise(const u64* __restrict__ a, co
     const ntt_limb_t L = LT[sel.idx[j]];
     const u64 q = L.q;
     const size_t base = (size_t)row * n;
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+    for (u32 i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
         const u64 x = a[base + i];
         u64 r;
         if (OP == OP_ADD) r = addmod(x, b[base + i], q);
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256) void k_tensor(const u64* __restrict__ a, const
         r2 = mulmod(x1, y1, L.br);
     };
     if ((n & 1u) == 0) {  // two coefficients per thread: 16-byte loads and stores
-        for (u32 i = threadIdx.x * 2; i < n; i += blockDim.x * 2) {
+        for (u32 i = (blockIdx.y * blockDim.x + threadIdx.x) * 2; i < n; i += gridDim.y * blockDim.x * 2) {
             const u64x2_t x0 = *(const u64x2_t*)(a0 + i), x1 = *(const u64x2_t*)(a1 + i);
             const u64x2_t y0 = *(const u64x2_t*)(b0 + i), y1 = *(const u64x2_t*)(b1 + i);
             u64x2_t r0, r1, r2;
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256) void k_tensor(const u64* __restrict__ a, const
         }
         return;
     }
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) one(a0[i], a1[i], b0[i], b1[i], o0[i], o1[i], o2[i]);
+    for (u32 i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) one(a0[i], a1[i], b0[i], b1[i], o0[i], o1[i], o2[i]);
 }
 
 // modswitch (crt.jl:215-228): rows = count*(limbs-1)
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_rescale(const u64* __restrict__ src, u6
     const u64* cj = src + ((size_t)p * nl + j) * n;
     const u64* cl = src + ((size_t)p * nl + nl - 1) * n;
     u64* d = dst + (size_t)row * n;
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+    for (u32 i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
         const u64 last = barrett_reduce128(cl[i], 0, L.br);  // unsigned representative of c_last, mod q_j
         d[i] = shoup_full(submod(cj[i], last, L.q), ra.qlinv[j], L.q);
     }
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(256) void k_select(const u64* __restrict__ src, u64
     const u32 row = blockIdx.x, j = row % (u32)which.n, p = row / (u32)which.n;
     const u64* s = src + ((size_t)p * src_limbs + which.idx[j]) * n;
     u64* d = dst + (size_t)row * n;
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+    for (u32 i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) d[i] = s[i];
 }
 
 // apply_galois_element (pow2_cyc_rings.jl:321-329) in gather form: out[r] = ± in[i], g*i ≡ r (mod N).
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_galois(const u64* __restrict__ src, u64
     const u64 q = LT[sel.idx[row % (u32)sel.n]].q;
     const size_t base = (size_t)row * n;
     const u64 mask2n = 2ull * n - 1;
-    for (u32 r = threadIdx.x; r < n; r += blockDim.x) {
+    for (u32 r = blockIdx.y * blockDim.x + threadIdx.x; r < n; r += gridDim.y * blockDim.x) {
         const u64 i0 = ((u64)r * ginv) & mask2n;
         const u64 v = src[base + (i0 & (n - 1))];
         dst[base + r] = (i0 >= n) ? negmod(v, q) : v;
@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(256) void k_ks_digits(const u64* __restrict__ ct, u
     lf.qi = LT[A.w.idx[i]].q; lf.half = lf.qi >> 1; lf.qj = LT[A.w.idx[j]].q; lf.bj = LT[A.w.idx[j]].br;
     const u64* c = ct + (((size_t)b * A.polys + (A.polys - 1)) * A.level + i) * n;
     u64* d = dig + (size_t)row * n;
-    for (u32 k = threadIdx.x; k < n; k += blockDim.x) d[k] = lift_digit(c[k], lf);
+    for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < n; k += gridDim.y * blockDim.x) d[k] = lift_digit(c[k], lf);
 }
 // Base-2^w digits of the key switch (relin_window != 0, rlwe_she.jl:330-338): digit i of convert(Integer, x) for every
 // coefficient x of c[end], x in [0, Q) reconstructed exactly from its residues (conv_core.h; a single limb is its own
@@ -1544,7 +1544,7 @@ __global__ __launch_bounds__(256) void k_ks_add_ct(const u64* __restrict__ ct, u
     const u64 q = LT[A.w.idx[j]].q;
     const u64* c = ct + (((size_t)b * A.polys + s) * A.level + j) * n;
     u64* o = out + (size_t)row * n;
-    for (u32 k = threadIdx.x; k < n; k += blockDim.x) o[k] = addmod(o[k], c[k], q);
+    for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < n; k += gridDim.y * blockDim.x) o[k] = addmod(o[k], c[k], q);
 }
 
 // ModulusRaised contraction fused with the "c +" of the key switch:  with x = P*c + S (limb-wise, special limb of
@@ -1560,7 +1560,7 @@ __global__ __launch_bounds__(256) void k_ks_rescale_add(const u64* __restrict__ 
     const u64* tl = T + (((size_t)b * 2 + s) * A.nw + A.level) * n;
     const u64* c = s < add_s ? ct + (((size_t)b * A.polys + s) * A.level + j) * n : nullptr;
     u64* o = out + (size_t)row * n;
-    for (u32 k = threadIdx.x; k < n; k += blockDim.x) {
+    for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < n; k += gridDim.y * blockDim.x) {
         const u64 last = barrett_reduce128(tl[k], 0, L.br);
         u64 v = shoup_full(submod(tj[k], last, L.q), ra.qlinv[j], L.q);
         if (c) v = addmod(v, c[k], L.q);

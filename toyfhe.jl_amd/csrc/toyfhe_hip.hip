@@ -388,6 +388,14 @@ int launch_bfv_core_fused(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64
     return TFHE_OK;
 }
 
+// grid of the row-wise kernels (one limb row per blockIdx.x): few rows -- a single ciphertext at N = 2^16 is 14 -- are
+// split over blockIdx.y so that the launch still covers the chip (about 2048 workgroups, at least 1024 coefficients each)
+static inline dim3 row_grid(unsigned rows, size_t n) {
+    const unsigned want = rows ? (2048u + rows - 1) / rows : 1u;
+    const unsigned cap = (unsigned)std::max<size_t>(1, n / 1024);
+    return dim3(rows, std::max(1u, std::min(want, cap)));
+}
+
 template <int OP>
 int run_pointwise(tfhe_ctx* c, const u64* a, const u64* b, const u64* acc, u64* dst, int64_t count, int limbs,
                   const int32_t* idx, const scal_arg_t* sc) {
@@ -399,7 +407,7 @@ int run_pointwise(tfhe_ctx* c, const u64* a, const u64* b, const u64* acc, u64* 
     if (count < 0 || count * limbs > 0x7fffffffll) return fail(TFHE_E_BADARG, "bad polynomial count");
     scal_arg_t s0;
     if (!sc) { memset(&s0, 0, sizeof s0); sc = &s0; }
-    hipLaunchKernelGGL(k_pointwise<OP>, dim3((unsigned)(count * limbs)), dim3(256), 0, c->stream, a, b, acc, dst,
+    hipLaunchKernelGGL(k_pointwise<OP>, row_grid((unsigned)(count * limbs), (size_t)c->N), dim3(256), 0, c->stream, a, b, acc, dst,
                        c->limbs_dev, sel, *sc, (u32)c->N);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
@@ -577,7 +585,7 @@ int tfhe_tensor(tfhe_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out
     int rc = make_sel(c, limbs, idx, &sel);
     if (rc) return rc;
     if (batch == 0) return TFHE_OK;
-    hipLaunchKernelGGL(k_tensor, dim3((unsigned)(batch * limbs)), dim3(256), 0, c->stream, a, b, out, c->limbs_dev, sel, (u32)c->N);
+    hipLaunchKernelGGL(k_tensor, row_grid((unsigned)(batch * limbs), (size_t)c->N), dim3(256), 0, c->stream, a, b, out, c->limbs_dev, sel, (u32)c->N);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
@@ -592,7 +600,7 @@ static int do_rescale(tfhe_ctx* c, const u64* src, u64* dst, int64_t count, cons
         ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(ql % qj, qj), qj);
     }
     if (count == 0) return TFHE_OK;
-    hipLaunchKernelGGL(k_rescale, dim3((unsigned)(count * (sel.n - 1))), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, ra, (u32)c->N);
+    hipLaunchKernelGGL(k_rescale, row_grid((unsigned)(count * (sel.n - 1)), (size_t)c->N), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, ra, (u32)c->N);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
@@ -614,7 +622,7 @@ int tfhe_select_limbs(tfhe_ctx* c, const uint64_t* src, uint64_t* dst, int64_t c
         w.idx[j] = which[j];
     }
     if (count == 0) return TFHE_OK;
-    hipLaunchKernelGGL(k_select, dim3((unsigned)(count * nw)), dim3(256), 0, c->stream, src, dst, w, src_limbs, (u32)c->N);
+    hipLaunchKernelGGL(k_select, row_grid((unsigned)(count * nw), (size_t)c->N), dim3(256), 0, c->stream, src, dst, w, src_limbs, (u32)c->N);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
@@ -627,7 +635,7 @@ static int do_galois(tfhe_ctx* c, const u64* src, u64* dst, u64 g, int64_t rows,
     u64 ginv = 1;  // inverse modulo 2N by Newton iteration (g odd)
     for (int i = 0; i < 6; i++) ginv = (ginv * (2 - g * ginv)) & (m - 1);
     if (rows == 0) return TFHE_OK;
-    hipLaunchKernelGGL(k_galois, dim3((unsigned)rows), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, ginv, (u32)c->N);
+    hipLaunchKernelGGL(k_galois, row_grid((unsigned)rows, (size_t)c->N), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, ginv, (u32)c->N);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
@@ -675,7 +683,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         memset(&ra, 0, sizeof ra);
         const u64 P = c->q[Lk - 1];
         for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
-        hipLaunchKernelGGL(k_ks_rescale_add, dim3((unsigned)(batch * 2 * level)), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
+        hipLaunchKernelGGL(k_ks_rescale_add, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
@@ -703,9 +711,9 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
             memset(&ra, 0, sizeof ra);
             const u64 P = c->q[Lk - 1];
             for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
-            hipLaunchKernelGGL(k_ks_rescale_add, dim3((unsigned)(batch * 2 * level)), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
+            hipLaunchKernelGGL(k_ks_rescale_add, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
         } else {
-            hipLaunchKernelGGL(k_ks_add_ct, dim3((unsigned)(batch * 2 * level)), dim3(256), 0, c->stream, ct, out, c->limbs_dev, A, n, add_s);
+            hipLaunchKernelGGL(k_ks_add_ct, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, ct, out, c->limbs_dev, A, n, add_s);
         }
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
@@ -719,7 +727,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         rc = run_ntt(c, false, ct, dig, batch * level * nw, A.w, &io);
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(k_ks_digits, dim3((unsigned)(batch * level * nw)), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n);
+        hipLaunchKernelGGL(k_ks_digits, row_grid((unsigned)(batch * level * nw), (size_t)c->N), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n);
         HIP_TRY(hipGetLastError());
         rc = run_ntt(c, false, dig, dig, batch * level * nw, A.w);
         if (rc) return rc;
@@ -744,7 +752,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         memset(&ra, 0, sizeof ra);
         const u64 P = c->q[Lk - 1];
         for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
-        hipLaunchKernelGGL(k_ks_rescale_add, dim3((unsigned)(batch * 2 * level)), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
+        hipLaunchKernelGGL(k_ks_rescale_add, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
@@ -756,7 +764,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
     }
     rc = run_ntt(c, true, S, out, batch * 2 * nw, A.w);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ks_add_ct, dim3((unsigned)(batch * 2 * level)), dim3(256), 0, c->stream, ct, out, c->limbs_dev, A, n, add_s);
+    hipLaunchKernelGGL(k_ks_add_ct, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, ct, out, c->limbs_dev, A, n, add_s);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
@@ -907,7 +915,7 @@ int tfhe_keyswitch_window(tfhe_ctx* c, int level, int window_bits, const uint64_
         } else {
             rc = run_ntt(c, true, S, cout, nb * 2 * level, A.w);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_ks_add_ct, dim3((unsigned)(nb * 2 * level)), dim3(256), 0, c->stream, cin, cout, c->limbs_dev, Al, n, add_s);
+            hipLaunchKernelGGL(k_ks_add_ct, row_grid((unsigned)(nb * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, cin, cout, c->limbs_dev, Al, n, add_s);
             HIP_TRY(hipGetLastError());
         }
     }
