@@ -1597,21 +1597,23 @@ __global__ __launch_bounds__(BFV_BS) void k_bfv_contract(const u64* __restrict__
 // register-resident fast path (bfv_fast.h): ℛbig = ℛ ∪ P with compile-time limb counts
 // copy_shared = 0: the limbs ℛbig shares with ℛ are not written -- k_bfv_core_fused transforms them straight out of the
 // input ciphertexts
-template <int NS, int NP>
+// NARROW (all moduli below TFHE_FP_QMAX, known to the host) selects the body at compile time: each kernel carries one
+// body and its register budget
+template <int NS, int NP, bool NARROW>
 __global__ __launch_bounds__(256) void k_bfv_expand_fast(const u64* __restrict__ src, u64* __restrict__ dst,
                                                           const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx, int copy_shared) {
     const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
     const size_t p = blockIdx.x / gx;
     if (k >= n) return;
-    if (Bt->narrow) bfv_expand_narrow<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
+    if constexpr (NARROW) bfv_expand_narrow<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
     else bfv_expand_fast<NS, NP, false>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
 }
-template <int NS, int NP>
+template <int NS, int NP, bool NARROW>
 __global__ __launch_bounds__(256) void k_bfv_contract_fast(const u64* __restrict__ src, u64* __restrict__ dst,
                                                             const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx) {
     const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
     const size_t p = blockIdx.x / gx;
     if (k >= n) return;
-    if (Bt->narrow) bfv_contract_narrow<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
+    if constexpr (NARROW) bfv_contract_narrow<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
     else bfv_contract_fast<NS, NP, false>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
 }
