@@ -58,7 +58,7 @@ int tfhe_ctx_psi(const tfhe_ctx *ctx, uint64_t *psi_out /* [L] */);
 int tfhe_ctx_set_stream(tfhe_ctx *ctx, void *hip_stream /* hipStream_t, NULL = library-owned */);
 int tfhe_ctx_sync(tfhe_ctx *ctx);
 /* choose the NTT kernel family: 0 = auto (register-blocked LDS kernel; exact-integer fp64 butterflies
- * when every selected modulus is < 1.125*2^50, u64 Shoup butterflies otherwise), 1 = force the generic
+ * when every selected modulus is < 2^50 + 2^40, u64 Shoup butterflies otherwise), 1 = force the generic
  * radix-2 kernel, 2 = force the u64 register-blocked kernel, 3 = fp64 kernels one operation per launch: no fused
  * BFV core / key-switch kernels, no next-row overlap (LDS-DMA staging in the inverse, register prefetch in the
  * forward), no read-once digit lift -- 1, 2 and 3 are cross-check paths for tests */

@@ -36,13 +36,13 @@ def test_ntt_bodies_match_oracle(logn, bits):
 
 @pytest.mark.parametrize("logn", [10, 12, 14])
 def test_fp64_butterflies_at_the_modulus_limit_and_worst_case_inputs(logn):
-    """fp64arith.h is valid for q < 1.125*2^50: take the largest NTT-friendly prime below that bound and
+    """fp64arith.h is valid for q < 2^50 + 2^40: take the largest NTT-friendly prime below that bound and
     inputs that maximise growth (all q-1, alternating 0 / q-1, all (q-1)/2)."""
     N = 1 << logn
-    q = (1266637395197952 // (2 * N)) * (2 * N) + 1
-    while q >= 1266637395197952 or not spec.is_prime(q):
+    q = (1126999418470400 // (2 * N)) * (2 * N) + 1
+    while q >= 1126999418470400 or not spec.is_prime(q):
         q -= 2 * N
-    assert q > 1.124 * 2**50
+    assert q > 2**50 + 2**40 - 2**30
     ctx = ref_cpu.RefCtx(N, [q])
     pats = [np.full(N, q - 1, dtype=np.uint64), np.array([0, q - 1] * (N // 2), dtype=np.uint64),
             np.full(N, (q - 1) // 2, dtype=np.uint64), np.random.default_rng(logn).integers(0, q, size=N, dtype=np.uint64)]

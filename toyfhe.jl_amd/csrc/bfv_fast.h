@@ -101,7 +101,7 @@ struct bfv_fast_tab_t {
     u64 n_cC2[TFHE_FAST_MAX][TFHE_FAST_MAX];    // [j][i]  (P/p_j) mod q_i
     u64 n_cNegA2[TFHE_FAST_MAX];                // -(P mod q_i)                 (times alpha_2)
     u64 n_cNegHalf[TFHE_FAST_MAX];              // -(floor(P/2) mod q_i)        (plain)
-    // exact-integer fp64 parts of the narrow path (every modulus below 1.125 * 2^50, fp64arith.h)
+    // exact-integer fp64 parts of the narrow path (every modulus below TFHE_FP_QMAX, fp64arith.h)
     double f_q[TFHE_FAST_MAX], f_qinv[TFHE_FAST_MAX];   // q_i, 1/q_i
     double f_p[TFHE_FAST_MAX], f_pinv[TFHE_FAST_MAX];   // p_j, 1/p_j
     double f_ea[TFHE_FAST_MAX], f_eb[TFHE_FAST_MAX];    // expand:   xi_i = x_i ea_i + eb_i mod q_i  (ea = (q/q_i)^-1, eb = floor(q/2) ea)
@@ -195,7 +195,7 @@ TFHE_HD void bfv_contract_fast(const bfv_fast_tab_t& B, const u64* src, size_t l
     }
 }
 
-// ---- narrow path: every modulus below 1.125 * 2^50 ----
+// ---- narrow path: every modulus below TFHE_FP_QMAX = 2^50 + 2^40 ----
 TFHE_HD u64 pack26(u64 c) { return (c & 0x3ffffffull) | ((c >> 26) << 32); }
 TFHE_HD void acc52_macp(acc52& a, u64 x, u64 cpacked) {
     acc52_mac(a, (u32)x & 0x3ffffffu, (u32)(x >> 26), (u32)cpacked, (u32)(cpacked >> 32));

@@ -1,4 +1,4 @@
-// fp64arith.h -- modular arithmetic on exact integers held in IEEE doubles, for primes p < 1.125 * 2^50.
+// fp64arith.h -- modular arithmetic on exact integers held in IEEE doubles, for primes p < 2^50 + 2^40.
 //
 // Why: on gfx950 a 64-bit Shoup butterfly costs ten 32-bit multiplier ops (v_mad_u64_u32 / v_mul_lo /
 // v_mul_hi, 4 cycles per wave64 each) plus carry chains; v_fma_f64 / v_mul_f64 / v_rndne_f64 issue at
@@ -11,16 +11,21 @@
 //                     r = fma(-k, p, h) + l                       (exact: |r| <= p (1/2 + 1.5 |y| 2^-52) < 2^53)
 // A twiddle is ONE double (8 bytes in the table, 2 VGPRs).  Values are kept as signed lazy
 // representatives; `reduce` brings |v| back to <= p/2 (+ tiny).
-// Range bookkeeping (in units of p, a = p 2^-52 <= 0.28125, growth per forward stage b' = b (1 + 1.5 a) + 1/2):
+// Range bookkeeping (in units of p; a = p 2^-52 <= 0.25 (1 + 2^-10), exactness limit 2^53 / p >= 7.99; growth per forward
+// stage b' = b (1 + 1.5 a) + 1/2 = 1.3754 b + 1/2).  The admissible range ends just above 2^50 on purpose: the moduli of
+// this size class are the primes next to 2^50 (the reference's rule takes the first NTT-friendly primes above it), and
+// with a <= 0.2503 five stages fit between two sweeps -- the old bound 1.125 * 2^50 allowed four.
 //   forward: residues enter uncentred (|v| <= 1); a sweep (reduce everything to <= 1/2) is planned before the first stage
-//        that would pass 7 (2^53 / p >= 7.1), across pass boundaries -- LDS holds lazy doubles (ntt_core.h
-//        fp_fwd_sweep_before):  1.92 3.23 5.09 | 1.21 2.22 3.66 5.70 | 1.21 ...  = one sweep per four stages
-//   inverse: sums double per stage, products return to <= 1/2 + 1.5 a b; only the operands whose sum would pass 7 p are
+//        that would pass 7.9, across pass boundaries -- LDS holds lazy doubles (ntt_core.h fp_fwd_sweep_before):
+//        1.88 3.08 4.73 7.01 | 1.19 2.13 3.43 5.22 7.68 | 1.19 ...  = two sweeps in a 14-stage block, 7.68 at its end
+//   inverse: sums double per stage, products return to <= 1/2 + 1.5 a b; only the operands whose sum would pass 7.9 p are
 //        reduced, by a compile-time plan (ntt_core.h make_inv_plan)
 #pragma once
 #include "modarith.h"
 
-#define TFHE_FP_QMAX 1266637395197952ull /* 1.125 * 2^50 */
+#define TFHE_FP_QMAX 1126999418470400ull /* 2^50 + 2^40 */
+#define TFHE_FP_A 0.25025          /* >= TFHE_FP_QMAX 2^-52 */
+#define TFHE_FP_LIMIT 7.9           /* < 2^53 / TFHE_FP_QMAX = 7.992 */
 
 struct ftw_t {  // twiddle w, an exact integer < p
     double w;

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
 #pragma unroll
                 for (int r = h * (E / 2); r < (h + 1) * (E / 2); r++) {
                     const u32 k = tid + ((u32)r << LOGT);
-                    // lifted digits enter loosely (|v| <= p, ArithFp::from_global_lift): lo + t <= 1.92 p before the reduction
+                    // lifted digits enter loosely (|v| <= p, ArithFp::from_global_lift): lo + t <= 1.88 p before the reduction
                     const double lo = LIFT ? A::from_global_lift(s[k], C, lf, true) : fp_from_u64(s[k]);
                     const double hv = LIFT ? A::from_global_lift(s[k + (1u << LOGB)], C, lf, true) : fp_from_u64(s[k + (1u << LOGB)]);
                     const double t = fp_mulmod_c(hv, w1, C.p, C.pinv);
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
                     const double x0 = xin[0], x1 = xin[1];
                     const double t2 = fp_mulmod_c(xin[2], w1, C.p, C.pinv);
                     const double t3 = fp_mulmod_c(xin[3], w1, C.p, C.pinv);
-                    // |y| <= 1.92 p, products <= 1.31 p (fp64arith.h); the sub-blocks take reduced operands
+                    // |y| <= 1.88 p, products <= 1.21 p (fp64arith.h); the sub-blocks take reduced operands
                     const double u0 = fp_mulmod_c(x1 + t3, w2, C.p, C.pinv), u1 = fp_mulmod_c(x1 - t3, w3, C.p, C.pinv);
                     w[0][h * (E / QC) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u0, x0 + t2), C.p, C.pinv));
                     w[1][h * (E / QC) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u1, x0 - t2), C.p, C.pinv));
@@ -1262,8 +1262,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
                     const int e = u * G3::R + r;
                     const typename A::tw k1{fp_from_u64(e_masked[nat])}, k0{fp_from_u64(e_mask[nat])};
-                    // range: y reduced to |y| <= p/2, so every term is <= (1/2 + 0.75 a) p = 0.72 p and eight of them stay
-                    // below the 7.1 p exactness limit (fp64arith.h); the accumulators are swept every eighth digit
+                    // range: y reduced to |y| <= p/2, so every term is <= (1/2 + 0.75 a) p = 0.69 p and eight of them stay
+                    // below the 7.9 p exactness limit (fp64arith.h); the accumulators are swept every eighth digit
                     const double y = fp_reduce(v[e], C.p, C.pinv);
                     acc[0][e] += fp_mulmod_c(y, k1, C.p, C.pinv);
                     acc[1][e] += fp_mulmod_c(y, k0, C.p, C.pinv);
@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                     TFHE_SCHED_FENCE();
 #pragma unroll
                     for (int r = 0; r < PE; r++) {
-                        // loosely lifted digits (|v| <= p): sums <= 1.92 p, products <= 1.31 p, <= 3.23 p before the reduction
+                        // loosely lifted digits (|v| <= p): sums <= 1.88 p, products <= 1.21 p, <= 3.09 p before the reduction
                         double xin[1 << X];
 #pragma unroll
                         for (int m = 0; m < (1 << X); m++) xin[m] = A::from_global_lift(q[m][r], C, lf, true);

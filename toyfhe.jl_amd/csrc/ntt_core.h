@@ -165,17 +165,17 @@ struct ArithInt {
 };
 
 // Forward range plan of the fp64 policy (fp64arith.h): a block's residues enter with |v| <= p (uncentred, or a loosely
-// lifted digit), every stage maps the bound b to b (1 + 1.5 a) + 1/2 with a = 0.28125, and a sweep (reduce every element
-// to |v| <= p/2) is placed before the first stage that would pass 7 p (exactness limit 2^53 / p >= 7.11).  The plan runs
-// over the block's stages regardless of the pass boundaries -- LDS holds lazy doubles -- which gives one sweep per four
-// stages: before stages 3, 7, 11 of a 2^14 block (bounds 1.92 3.23 5.09 | 1.21 2.22 3.66 5.70 | ...), and 3.66 p at the end.
+// lifted digit), every stage maps the bound b to b (1 + 1.5 a) + 1/2 with a = TFHE_FP_A, and a sweep (reduce every element
+// to |v| <= p/2) is placed before the first stage that would pass TFHE_FP_LIMIT p.  The plan runs over the block's stages
+// regardless of the pass boundaries -- LDS holds lazy doubles: sweeps before stages 4 and 9 of a 2^14 block (bounds
+// 1.88 3.08 4.73 7.01 | 1.19 2.13 3.43 5.22 7.68 | 1.19 ... 7.68 at the end; every consumer reduces or canonicalises).
 constexpr bool fp_fwd_sweep_before(int nstages, int s) {
     double b = 1.0;
     for (int t = 0; t < nstages; t++) {
-        const bool sweep = b * 1.421875 + 0.5 > 7.0;
+        const bool sweep = b * (1.0 + 1.5 * TFHE_FP_A) + 0.5 > TFHE_FP_LIMIT;
         if (t == s) return sweep;
         if (sweep) b = 0.5001;
-        b = b * 1.421875 + 0.5;
+        b = b * (1.0 + 1.5 * TFHE_FP_A) + 0.5;
     }
     return false;
 }
@@ -449,15 +449,15 @@ TFHE_HD void inv_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, i
 // Range plan of an inverse pass (fp64 policy): sums double per Gentleman-Sande stage while products come back to
 // <= 1/2 + 1.5 a b, so only the elements on long runs of sums ever approach the exactness limit.  Instead of sweeping
 // all 2^K registers every third stage, reduce exactly the operands whose sum would exceed the limit (bounds in units of
-// p for the worst admissible modulus, a = 1.125 * 2^50 / 2^52; limit 7 < 2^53 / (1.125 * 2^50)): 10 reductions in a
-// 5-stage pass instead of 32, 2 instead of 16 in a 4-stage pass.  mask[s] = registers reduced before processed stage s.
+// p for the worst admissible modulus, a = TFHE_FP_A, limit TFHE_FP_LIMIT < 2^53 / TFHE_FP_QMAX).
+// mask[s] = registers reduced before processed stage s.
 struct inv_plan_t {
     u32 mask[8];
 };
 template <int K>
 constexpr inv_plan_t make_inv_plan() {
     inv_plan_t P{};
-    constexpr double a = 0.28125, lim = 7.0, b0 = 0.502;
+    constexpr double a = TFHE_FP_A, lim = TFHE_FP_LIMIT, b0 = 0.502;
     double b[1 << K] = {};
     for (int i = 0; i < (1 << K); i++) b[i] = b0;
     for (int st = 0; st < K; st++) {
