@@ -1484,7 +1484,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
                 for (int r = 0; r < G3::R; r++) {
                     const int e = u * G3::R + r;
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
-                    srow[nat] = fp_canon(fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv), C.p, C.pinv);   // a1 b0, parked
+                    srow[nat] = A::to_lds(fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv));               // a1 b0, parked as a lazy double
                     v[e] = fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv);                                // a0 b0, in place
                 }
             }
@@ -1501,7 +1501,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
                 for (int r = 0; r < G3::R; r++) {
                     const int e = u * G3::R + r;
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
-                    A0[e] = fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv) + fp_from_u64(srow[nat]);
+                    A0[e] = fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv) + A::from_lds(srow[nat]);
                     A1[e] = fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv);
                 }
             }
