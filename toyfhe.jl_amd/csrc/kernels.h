@@ -1216,8 +1216,22 @@ __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* 
 // natural-order register map.  HBM traffic per ciphertext: `level` source rows + (polys-1)*level addend rows read and
 // 2*level rows written, instead of writing and re-reading level*level digit rows and 2*level accumulator rows.
 // ------------------------------------------------------------------------------------------------
+// The key rows a call needs, as doubles: evd[(i*2 + comp)*nw + j] = double(evk[(i*2 + comp)*Lk + w.idx[j]]) (bit patterns).
+// One small launch per key switch call (level*2*nw rows) takes the two u64 -> double conversions per key word out of the
+// fused kernel's inner product, where every word is used once per ciphertext of the batch.
+__global__ __launch_bounds__(256) void k_evk_to_f64(const u64* __restrict__ evk, u64* __restrict__ evd, ks_arg_t KA, int Lk, u32 n) {
+    const u32 row = blockIdx.x, j = row % (u32)KA.nw, ic = row / (u32)KA.nw;
+    const u64* s = evk + ((size_t)ic * Lk + KA.w.idx[j]) * n;
+    u64* d = evd + (size_t)row * n;
+    for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < n; k += gridDim.y * blockDim.x) {
+        const double v = fp_from_u64(s[k]);
+        u64 b;
+        __builtin_memcpy(&b, &v, 8);
+        d[k] = b;
+    }
+}
 template <class A, int LOGB, int LOGT>
-__global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ evk, const u64* __restrict__ ct,
+__global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ evd, const u64* __restrict__ ct,
                                                          u64* __restrict__ out, const ntt_limb_t* __restrict__ LT,
                                                          ks_arg_t KA, int Lk, u32 nitems) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
@@ -1251,8 +1265,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
             typename A::elem v[E];
             fused_fwd_to_regs<A, LOGB, LOGT>(lds, grow, C, first, v, &lf);
             // multiply-accumulate with the key: component 1 (masked) feeds out_0, component 0 (mask) feeds out_1
-            const u64* e_mask = evk + (((size_t)i * 2 + 0) * Lk + KA.w.idx[j] << LOGB);
-            const u64* e_masked = evk + (((size_t)i * 2 + 1) * Lk + KA.w.idx[j] << LOGB);
+            const u64* e_mask = evd + (((size_t)i * 2 + 0) * nw + j << LOGB);    // key words as doubles (k_evk_to_f64)
+            const u64* e_masked = evd + (((size_t)i * 2 + 1) * nw + j << LOGB);
 #pragma unroll
             for (int u = 0; u < G3::SETS; u++) {
                 u32 c0, hi, base;
@@ -1261,7 +1275,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
                 for (int r = 0; r < G3::R; r++) {
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
                     const int e = u * G3::R + r;
-                    const typename A::tw k1{fp_from_u64(e_masked[nat])}, k0{fp_from_u64(e_mask[nat])};
+                    const typename A::tw k1{A::from_lds(e_masked[nat])}, k0{A::from_lds(e_mask[nat])};
                     // range: y reduced to |y| <= p/2, so every term is <= (1/2 + 0.75 a) p = 0.69 p and eight of them stay
                     // below the 7.9 p exactness limit (fp64arith.h); the accumulators are swept every eighth digit
                     const double y = fp_reduce(v[e], C.p, C.pinv);

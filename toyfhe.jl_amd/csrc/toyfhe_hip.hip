@@ -652,8 +652,16 @@ int tfhe_galois(tfhe_ctx* c, const uint64_t* src, uint64_t* dst, uint64_t g, int
 // transforming:  out_s = c_s + INTT(S_s)  (plain)   or   c_s + modswitch-part of INTT(S_s)  (ModulusRaised),
 // with S_s = Σ_i evk_{i,s} ⊙ NTT(digit_i)  (see k_ks_inner, k_ks_rescale_add).
 //   dig: [batch][level][nw][N]  NTT'd digits      S: [batch][2][nw][N]
+// the fused N = 2^14 key switch (k_ks_fused) reads the key as doubles, prepared once per call by ks_prepare_key
+static bool ks_fused14(const tfhe_ctx* c, int Lk, int level, int special) {
+    limb_sel_t w;
+    w.n = special ? level + 1 : level;
+    for (int j = 0; j < level; j++) w.idx[j] = j;
+    if (special) w.idx[level] = Lk - 1;
+    return c->logN == 14 && c->variant == 0 && sel_fp(c, w, 0);
+}
 static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
-                    u64* S, u64* dig) {
+                    u64* S, u64* dig, const u64* evd) {
     const int nw = special ? level + 1 : level;
     ks_arg_t A;
     memset(&A, 0, sizeof A);
@@ -664,7 +672,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
     const u32 n = (u32)c->N;
     const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
     int rc;
-    if (c->logN == 14 && c->variant == 0 && sel_fp(c, A.w, 0)) {
+    if (evd) {  // ks_fused14
         // everything in one kernel: digit lift, forward transforms, key inner product and the two inverse transforms;
         // with the special prime the transformed sums go to S and the contraction kernel finishes (modulusraising.jl:42)
         constexpr int LOGT = logt_for(14);
@@ -675,7 +683,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         const unsigned items = (unsigned)(batch * nw);
         const unsigned grid = std::min(items, (unsigned)c->num_cus);
         prof_begin(c, (int64_t)items * (level + 2));  // limb transforms inside this launch: `level` forward + 2 inverse per item
-        hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evk, ct, special ? S : out, c->limbs_dev, A, Lk, items);
+        hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, special ? S : out, c->limbs_dev, A, Lk, items);
         prof_end(c);
         HIP_TRY(hipGetLastError());
         if (!special) return TFHE_OK;
@@ -790,12 +798,26 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
     void* ws = nullptr;
     // NTT of N > 2^14 uses the context workspace as well: keep ours separate by over-allocating
     const size_t ntt_tmp = c->logN > 14 ? (size_t)chunk * std::max(2, level) * nw * N * 8 : 0;
-    int rc = ensure_ws(c, ntt_tmp + chunk * per_ct, &ws);
+    const bool f14 = ks_fused14(c, Lk, level, special);
+    const size_t evd_bytes = f14 ? (size_t)level * 2 * nw * N * 8 : 0;  // the key rows of this call as doubles
+    int rc = ensure_ws(c, ntt_tmp + chunk * per_ct + evd_bytes, &ws);
     if (rc) return rc;
     u64* base = (u64*)((char*)ws + ntt_tmp);
     u64* acc = base;
     u64* dig = acc + (size_t)chunk * 2 * nw * N;
     u64* rot = dig + (size_t)chunk * level * nw * N;
+    u64* evd = nullptr;
+    if (f14) {
+        evd = (u64*)((char*)ws + ntt_tmp + chunk * per_ct);
+        ks_arg_t KA;
+        memset(&KA, 0, sizeof KA);
+        KA.level = level; KA.nw = nw; KA.special = special; KA.polys = polys;
+        KA.w.n = nw;
+        for (int j = 0; j < level; j++) KA.w.idx[j] = j;
+        if (special) KA.w.idx[level] = Lk - 1;
+        hipLaunchKernelGGL(k_evk_to_f64, row_grid((unsigned)(level * 2 * nw), N), dim3(256), 0, c->stream, evk, evd, KA, Lk, (u32)N);
+        HIP_TRY(hipGetLastError());
+    }
     for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
         const int64_t nb = std::min(chunk, batch - b0);
         const u64* cin = ct + (size_t)b0 * polys * level * N;
@@ -807,7 +829,7 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
             if (rc) return rc;
             cin = rot;
         }
-        rc = ks_chunk(c, Lk, level, special, evk, cin, polys, out + (size_t)b0 * 2 * level * N, nb, acc, dig);
+        rc = ks_chunk(c, Lk, level, special, evk, cin, polys, out + (size_t)b0 * 2 * level * N, nb, acc, dig, evd);
         if (rc) return rc;
     }
     return TFHE_OK;
