@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 // and share the source rows in its L2.
 // ------------------------------------------------------------------------------------------------
 template <class A, int LOGB, int LOGT, int X>
-__global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restrict__ evk, const u64* __restrict__ ct,
+__global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restrict__ evd, const u64* __restrict__ ct,
                                                              u64* __restrict__ T, const ntt_limb_t* __restrict__ LT,
                                                              ks_arg_t KA, int Lk, u32 nitems) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
@@ -1394,8 +1394,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, pre);
             }
             // multiply-accumulate with the key words at natural-order positions 2 nat + sb
-            const u64* e_mask = evk + (((size_t)i * 2 + 0) * Lk + KA.w.idx[j] << (LOGB + X)) + brev_bits(sb, X);
-            const u64* e_masked = evk + (((size_t)i * 2 + 1) * Lk + KA.w.idx[j] << (LOGB + X)) + brev_bits(sb, X);
+            const u64* e_mask = evd + (((size_t)i * 2 + 0) * nw + j << (LOGB + X)) + brev_bits(sb, X);    // doubles (k_evk_to_f64)
+            const u64* e_masked = evd + (((size_t)i * 2 + 1) * nw + j << (LOGB + X)) + brev_bits(sb, X);
 #pragma unroll
             for (int u = 0; u < G3::SETS; u++) {
                 u32 c0, hi, base;
@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 for (int r = 0; r < G3::R; r++) {
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
                     const int e = u * G3::R + r;
-                    const typename A::tw k1{fp_from_u64(e_masked[nat << X])}, k0{fp_from_u64(e_mask[nat << X])};
+                    const typename A::tw k1{A::from_lds(e_masked[nat << X])}, k0{A::from_lds(e_mask[nat << X])};
                     const double y = fp_reduce(v[e], C.p, C.pinv);  // range: as k_ks_fused
                     acc[0][e] += fp_mulmod_c(y, k1, C.p, C.pinv);
                     acc[1][e] += fp_mulmod_c(y, k0, C.p, C.pinv);

@@ -652,13 +652,16 @@ int tfhe_galois(tfhe_ctx* c, const uint64_t* src, uint64_t* dst, uint64_t g, int
 // transforming:  out_s = c_s + INTT(S_s)  (plain)   or   c_s + modswitch-part of INTT(S_s)  (ModulusRaised),
 // with S_s = Σ_i evk_{i,s} ⊙ NTT(digit_i)  (see k_ks_inner, k_ks_rescale_add).
 //   dig: [batch][level][nw][N]  NTT'd digits      S: [batch][2][nw][N]
-// the fused N = 2^14 key switch (k_ks_fused) reads the key as doubles, prepared once per call by ks_prepare_key
+// the fused key switches (k_ks_fused at N = 2^14, k_ks_fused_sub at 2^15) read the key as doubles, prepared once per call
+// (k_evk_to_f64 in keyswitch_impl)
 static bool ks_fused14(const tfhe_ctx* c, int Lk, int level, int special) {
     limb_sel_t w;
     w.n = special ? level + 1 : level;
     for (int j = 0; j < level; j++) w.idx[j] = j;
     if (special) w.idx[level] = Lk - 1;
-    return c->logN == 14 && c->variant == 0 && sel_fp(c, w, 0);
+    if (c->variant != 0) return false;
+    if (c->logN == 14) return sel_fp(c, w, 0);
+    return c->logN == 15 && level >= 2 && sel_fp(c, w, 1);  // k_ks_fused_sub
 }
 static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
                     u64* S, u64* dig, const u64* evd) {
@@ -672,7 +675,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
     const u32 n = (u32)c->N;
     const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
     int rc;
-    if (evd) {  // ks_fused14
+    if (evd && c->logN == 14) {  // ks_fused14
         // everything in one kernel: digit lift, forward transforms, key inner product and the two inverse transforms;
         // with the special prime the transformed sums go to S and the contraction kernel finishes (modulusraising.jl:42)
         constexpr int LOGT = logt_for(14);
@@ -695,7 +698,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
-    if (c->logN == 15 && c->variant == 0 && sel_fp(c, A.w, 1) && level >= 2) {
+    if (evd && c->logN == 15) {  // ks_fused14: variant 0, fp64 policy, level >= 2
         // N = 2^15: per-sub-block fused key switch (k_ks_fused_sub) into T = dig ([batch][2][nw] rows, level >= 2 makes
         // room), then the inverse top stage over T and the usual tail.  (The X = 2 instance for N = 2^16 measured slower
         // than the three-kernel path below: 235 spilled registers next to the 128 accumulator registers.)
@@ -708,7 +711,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         const unsigned items = (unsigned)((batch * nw) << x);
         const unsigned grid = std::min(items, (unsigned)c->num_cus);
         prof_begin(c, (int64_t)batch * nw * (level + 2));
-        hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evk, ct, dig, c->limbs_dev, A, Lk, items);
+        hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, dig, c->limbs_dev, A, Lk, items);
         prof_end(c);
         HIP_TRY(hipGetLastError());
         const dim3 tg((unsigned)((((n >> x) + 255) / 256) * (batch * 2 * nw)));
