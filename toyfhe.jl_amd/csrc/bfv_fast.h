@@ -251,8 +251,23 @@ TFHE_HD void bfv_expand_narrow(const bfv_fast_tab_t& B, const u64* src, size_t l
     }
 }
 
+// centred residue r - q (r > q/2) or r of a canonical word, as the bit pattern of the exact double (|value| < 2^51):
+// integer centring, then the 2^52 trick on value + 2^51
+TFHE_HD u64 centred_double_bits(u64 r, u64 q) {
+    const u64 s = r > (q >> 1) ? r - q : r;                       // two's complement of the centred value
+    const u64 bits = (s + (1ull << 51)) | 0x4330000000000000ull;  // 2^52 + (value + 2^51), value + 2^51 in [0, 2^52)
+    double d;
+    __builtin_memcpy(&d, &bits, 8);
+    d -= 6755399441055744.0;                                      // 2^52 + 2^51
+    u64 out;
+    __builtin_memcpy(&out, &d, 8);
+    return out;
+}
+// lifted_out: the residues are written as CENTRED DOUBLES (bit patterns) instead of canonical words -- the form the fused key
+// switch lifts its digit rows into (rlwe_she.jl:326-329); used for the c2 polynomial of a multiplication that is
+// relinearised next (internal buffer of tfhe_bfv_mul_relin only)
 template <int NS, int NP>
-TFHE_HD void bfv_contract_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld) {
+TFHE_HD void bfv_contract_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld, bool lifted_out = false) {
     u64 xi[NS];
     double xd[NS];
 #pragma unroll
@@ -280,6 +295,7 @@ TFHE_HD void bfv_contract_narrow(const bfv_fast_tab_t& B, const u64* src, size_t
 #pragma unroll
         for (int j = 0; j < NP; j++) acc52_macp(a, xp[j], B.n_cC2[j][i]);
         acc52_macp(a, (u64)a2, B.n_cNegA2[i]);
-        dst[(size_t)i * ld] = acc52_reduce(a, B.qb[i]);
+        const u64 r = acc52_reduce(a, B.qb[i]);
+        dst[(size_t)i * ld] = lifted_out ? centred_double_bits(r, B.qb[i].q) : r;
     }
 }

@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk
 
 // ---- shared pieces of the fused kernels: a forward transform that ends in registers (last pass's natural-order map)
 // and an inverse transform that starts from registers in that same map ----
-template <class A, int LOGB, int LOGT>
+template <class A, int LOGB, int LOGT, bool PRELIFT = false>
 __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, const typename A::ctx& C, bool& first,
                                                   typename A::elem* v, const lift_t* lift = nullptr) {
     constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
@@ -1173,7 +1173,19 @@ __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, con
         fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, grow, tid);
         if (!first) __syncthreads();  // the previous transform's last pass has read LDS
         first = false;
-        fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u, lift);
+        if constexpr (PRELIFT) {
+            // The words are centred doubles already (|d| <= q_i / 2 <= p: the host admits this path only when no modulus is
+            // more than twice another): element bits, as if they came from LDS.  Every operand
+            // is pinned before the first butterfly: left to itself the compiler spreads the waits for these loads over the
+            // butterflies, which measured 22 % slower on the whole kernel (1.61 ms pinned, 2.05 ms unpinned, 1.67 ms with
+            // the in-kernel lift, whose conversion loop has the same effect as the pins).
+#pragma unroll
+            for (int i = 0; i < E; i++) pin_vgpr(raw[i]);
+            TFHE_SCHED_FENCE();
+            fwd_compute<A, LOGB, LOGT, 0, K1, false, false, 0>(v, raw, nullptr, C, tid, 1u);
+        } else {
+            fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u, lift);
+        }
         fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
     }
     __syncthreads();
@@ -1230,7 +1242,8 @@ __global__ __launch_bounds__(256) void k_evk_to_f64(const u64* __restrict__ evk,
         d[k] = b;
     }
 }
-template <class A, int LOGB, int LOGT>
+// PRELIFT: the rows of c[end] arrive as centred doubles (bfv_contract_narrow<.., LIFTED>): the lift is a bit cast
+template <class A, int LOGB, int LOGT, bool PRELIFT = false>
 __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ evd, const u64* __restrict__ ct,
                                                          u64* __restrict__ out, const ntt_limb_t* __restrict__ LT,
                                                          ks_arg_t KA, int Lk, u32 nitems) {
@@ -1263,7 +1276,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
             lf.half = lf.qi >> 1;
             const u64* grow = ct + ((size_t)((b * polys + polys - 1) * level + i) << LOGB);
             typename A::elem v[E];
-            fused_fwd_to_regs<A, LOGB, LOGT>(lds, grow, C, first, v, &lf);
+            fused_fwd_to_regs<A, LOGB, LOGT, PRELIFT>(lds, grow, C, first, v, &lf);
             // multiply-accumulate with the key: component 1 (masked) feeds out_0, component 0 (mask) feeds out_1
             const u64* e_mask = evd + (((size_t)i * 2 + 0) * nw + j << LOGB);    // key words as doubles (k_evk_to_f64)
             const u64* e_masked = evd + (((size_t)i * 2 + 1) * nw + j << LOGB);
@@ -1622,12 +1635,18 @@ __global__ __launch_bounds__(256) void k_bfv_expand_fast(const u64* __restrict__
     if constexpr (NARROW) bfv_expand_narrow<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
     else bfv_expand_fast<NS, NP, false>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
 }
-template <int NS, int NP, bool NARROW>
+// LIFT3 (narrow bodies, products: three polynomials per ciphertext): every third polynomial (c2) leaves as centred doubles
+// for the fused key switch (bfv_contract_narrow, lifted_out: workgroup-uniform).
+template <int NS, int NP, bool NARROW, bool LIFT3 = false>
 __global__ __launch_bounds__(256) void k_bfv_contract_fast(const u64* __restrict__ src, u64* __restrict__ dst,
                                                             const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx) {
     const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
-    const size_t p = blockIdx.x / gx;
+    const u32 b = blockIdx.x / gx;
+    const size_t p = b;
     if (k >= n) return;
-    if constexpr (NARROW) bfv_contract_narrow<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
-    else bfv_contract_fast<NS, NP, false>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
+    if constexpr (NARROW) {
+        bfv_contract_narrow<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n, LIFT3 && b % 3u == 2u);
+    } else {
+        bfv_contract_fast<NS, NP, false>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
+    }
 }

@@ -663,8 +663,15 @@ static bool ks_fused14(const tfhe_ctx* c, int Lk, int level, int special) {
     if (c->logN == 14) return sel_fp(c, w, 0);
     return c->logN == 15 && level >= 2 && sel_fp(c, w, 1);  // k_ks_fused_sub
 }
+// pre-lifted c[end] rows (centred doubles from the BFV contraction) are understood by k_ks_fused only
+static bool ks_prelift_ok(const tfhe_ctx* c, int level) {
+    if (c->logN != 14 || !ks_fused14(c, level, level, 0)) return false;
+    u64 lo = ~0ull, hi = 0;  // the bit-cast lift keeps |digit| <= q_i / 2 unreduced: needs q_i <= 2 q_j for every pair
+    for (int j = 0; j < level; j++) { lo = std::min(lo, c->q[j]); hi = std::max(hi, c->q[j]); }
+    return hi <= 2 * lo;
+}
 static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
-                    u64* S, u64* dig, const u64* evd) {
+                    u64* S, u64* dig, const u64* evd, bool prelifted) {
     const int nw = special ? level + 1 : level;
     ks_arg_t A;
     memset(&A, 0, sizeof A);
@@ -680,9 +687,14 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         // with the special prime the transformed sums go to S and the contraction kernel finishes (modulusraising.jl:42)
         constexpr int LOGT = logt_for(14);
         const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
-        auto fk = k_ks_fused<ArithFp, 14, LOGT>;
+        auto fk = prelifted ? k_ks_fused<ArithFp, 14, LOGT, true> : k_ks_fused<ArithFp, 14, LOGT, false>;
         static bool fattr_set = false;
-        if (!fattr_set) { rc = set_lds(fk, lds); if (rc) return rc; fattr_set = true; }
+        if (!fattr_set) {
+            rc = set_lds(k_ks_fused<ArithFp, 14, LOGT, true>, lds);
+            if (!rc) rc = set_lds(k_ks_fused<ArithFp, 14, LOGT, false>, lds);
+            if (rc) return rc;
+            fattr_set = true;
+        }
         const unsigned items = (unsigned)(batch * nw);
         const unsigned grid = std::min(items, (unsigned)c->num_cus);
         prof_begin(c, (int64_t)items * (level + 2));  // limb transforms inside this launch: `level` forward + 2 inverse per item
@@ -792,7 +804,8 @@ static int ks_check(tfhe_ctx* c, int Lk, int level, int special, const void* evk
 }
 
 static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
-                          u64 galois, bool rotate) {
+                          u64 galois, bool rotate, bool prelifted = false) {
+    if (prelifted && (rotate || special || !ks_prelift_ok(c, level))) return fail(TFHE_E_UNSUPPORTED, "internal: pre-lifted rows need the fused key switch");
     const int nw = special ? level + 1 : level;
     const size_t N = (size_t)c->N;
     // chunk the batch so that the digit tensor stays at a few hundred MiB
@@ -832,7 +845,7 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
             if (rc) return rc;
             cin = rot;
         }
-        rc = ks_chunk(c, Lk, level, special, evk, cin, polys, out + (size_t)b0 * 2 * level * N, nb, acc, dig, evd);
+        rc = ks_chunk(c, Lk, level, special, evk, cin, polys, out + (size_t)b0 * 2 * level * N, nb, acc, dig, evd, prelifted);
         if (rc) return rc;
     }
     return TFHE_OK;
