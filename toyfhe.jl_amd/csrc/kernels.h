@@ -49,7 +49,7 @@ __device__ __forceinline__ void fwd_schedule(u64* lds, const u64* gsrc, u64* gds
 // ---- inverse schedule with the twiddles of pass p+1 requested before the LDS exchange that ends pass p (8-byte fp64
 // twiddles: a whole pass's set fits the register budget of a 512-thread workgroup).  +9 % for the inverse transform; the
 // same idea measured slower for the forward one, which keeps the simple schedule. ----
-template <class A, int LOGB, int LOGT, int SEND>
+template <class A, int LOGB, int LOGT, int SEND, bool SCALE = true>
 __device__ __forceinline__ void inv_schedule_ptw(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
                                                  u32 pre, const u64* addend, const typename A::tw* tw_cur) {
     constexpr int K = pass_k_inv(LOGB, LOGT, SEND);
@@ -61,17 +61,17 @@ __device__ __forceinline__ void inv_schedule_ptw(u64* lds, const u64* gsrc, u64*
     inv_load_data<LOGB, LOGT, S0, K, FROM_GLOBAL>(raw, lds, gsrc, tid, 0, 0u);
     // the last pass (S0 == 0) has workgroup-uniform twiddles: loaded inside (scalar); the first one loads its own
     // alongside the operands; the middle ones come prefetched
-    inv_compute<A, LOGB, LOGT, S0, K, FROM_GLOBAL, true, (TO_GLOBAL || FROM_GLOBAL) ? 0 : K>(v, raw, tw_cur, C, tid, pre);
+    inv_compute<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE, (TO_GLOBAL || FROM_GLOBAL) ? 0 : K>(v, raw, tw_cur, C, tid, pre);
     if constexpr (!TO_GLOBAL) {
         constexpr int K2 = pass_k_inv(LOGB, LOGT, S0);
         typedef pgeom<LOGB, LOGT, S0 - K2, K2> G2;
         typename A::tw tw_next[G2::SETS * G2::NTW];
         if constexpr (S0 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S0 - K2, K2, false>(tw_next, C, tid, pre);
-        inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, true>(v, lds, gdst, C, tid, nullptr);
+        inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid, nullptr);
         __syncthreads();
-        inv_schedule_ptw<A, LOGB, LOGT, S0>(lds, gsrc, gdst, C, tid, pre, addend, tw_next);
+        inv_schedule_ptw<A, LOGB, LOGT, S0, SCALE>(lds, gsrc, gdst, C, tid, pre, addend, tw_next);
     } else {
-        inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, true>(v, lds, gdst, C, tid, addend);
+        inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid, addend);
     }
 }
 
@@ -1199,7 +1199,9 @@ __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, con
 }
 // inverse transform of elements held in the forward-last-pass register map (v is reduced here and consumed); result
 // (+ addend) to gdst
-template <class A, int LOGB, int LOGT>
+// SCALE = false: the caller has folded N^-1 into its operands (k_ks_fused: into the key rows), the last stage is a plain
+// butterfly instead of two scaling products per pair
+template <class A, int LOGB, int LOGT, bool SCALE = true>
 __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* v, u64* gdst, const typename A::ctx& C, const u64* addend) {
     constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB);
     constexpr int E = 1 << (LOGB - LOGT);
@@ -1211,12 +1213,12 @@ __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* 
     {
 #pragma unroll
         for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], C.p, C.pinv);
-        inv_compute<A, LOGB, LOGT, S1, KI1, true, true, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, 1u);
+        inv_compute<A, LOGB, LOGT, S1, KI1, true, SCALE, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, 1u);
         if constexpr (S1 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S1 - K2, K2, false>(tw_next, C, tid, 1u);
-        inv_store<A, LOGB, LOGT, S1, KI1, true, true>(v, lds, nullptr, C, tid);
+        inv_store<A, LOGB, LOGT, S1, KI1, true, SCALE>(v, lds, nullptr, C, tid);
     }
     __syncthreads();
-    inv_schedule_ptw<A, LOGB, LOGT, S1>(lds, nullptr, gdst, C, tid, 1u, addend, tw_next);
+    inv_schedule_ptw<A, LOGB, LOGT, S1, SCALE>(lds, nullptr, gdst, C, tid, 1u, addend, tw_next);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1231,12 +1233,19 @@ __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* 
 // The key rows a call needs, as doubles: evd[(i*2 + comp)*nw + j] = double(evk[(i*2 + comp)*Lk + w.idx[j]]) (bit patterns).
 // One small launch per key switch call (level*2*nw rows) takes the two u64 -> double conversions per key word out of the
 // fused kernel's inner product, where every word is used once per ciphertext of the batch.
-__global__ __launch_bounds__(256) void k_evk_to_f64(const u64* __restrict__ evk, u64* __restrict__ evd, ks_arg_t KA, int Lk, u32 n) {
+// fold_ninv: the words are multiplied by N^-1 mod q_j on the way (k_ks_fused runs its inverse transforms unscaled).
+__global__ __launch_bounds__(256) void k_evk_to_f64(const u64* __restrict__ evk, u64* __restrict__ evd,
+                                                     const ntt_limb_t* __restrict__ LT, ks_arg_t KA, int Lk, u32 n, int fold_ninv) {
     const u32 row = blockIdx.x, j = row % (u32)KA.nw, ic = row / (u32)KA.nw;
+    const ntt_limb_t& L = LT[KA.w.idx[j]];
     const u64* s = evk + ((size_t)ic * Lk + KA.w.idx[j]) * n;
     u64* d = evd + (size_t)row * n;
     for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < n; k += gridDim.y * blockDim.x) {
-        const double v = fp_from_u64(s[k]);
+        double v = fp_from_u64(s[k]);
+        if (fold_ninv) {
+            v = fp_mulmod_c(v, L.ninv_d, L.pd, L.pinvd);
+            v = v < 0.0 ? v + L.pd : v;
+        }
         u64 b;
         __builtin_memcpy(&b, &v, 8);
         d[k] = b;
@@ -1309,7 +1318,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
         for (int sidx = 0; sidx < 2; sidx++) {
             const u64* addend = (!KA.special && (u32)sidx < add_s) ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : nullptr;
             u64* gdst = out + ((size_t)((b * 2 + sidx) * nw + j) << LOGB);
-            fused_inv_from_regs<A, LOGB, LOGT>(lds, acc[sidx], gdst, C, addend);
+            fused_inv_from_regs<A, LOGB, LOGT, false>(lds, acc[sidx], gdst, C, addend);  // N^-1 is in the key rows (k_evk_to_f64)
         }
     }
 }

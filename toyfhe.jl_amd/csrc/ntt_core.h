@@ -548,7 +548,7 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
             const u32 j = base + ((u32)r << G::LO);
             if (TO_GLOBAL) {
                 u64 w = o[u * G::R + r];
-                if (SCALE && addend) w = addmod(w, addend[j], C.q);
+                if (addend) w = addmod(w, addend[j], C.q);
                 gdst[j] = w;
             } else {
                 typename A::elem e = v[u * G::R + r];
