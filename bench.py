@@ -100,7 +100,7 @@ def main():
     # tools/pmc_bench.py over this very script at batch 256).  bench.py cannot run the counters itself, so it scales the
     # committed per-ciphertext figure of the two transform-carrying kernels to this run's launches.
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_bench_kernels.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01r_pmc_bench_kernels.json")
     if os.path.exists(pmc_path) and launches:
         pmc = json.load(open(pmc_path))
         per_ct = sum(k["hbm_bytes_per_launch"] for name, k in pmc["kernels"].items() if "fused" in name) / pmc["batch"]
@@ -126,7 +126,7 @@ def main():
                                "transforms x 2*N*8 algorithmic bytes (SURVEY 8d), durations by HIP events around these launches",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the two kernels, "
-                                                         "profiles/r01_pmc_bench_kernels.json, scaled to this run's launches); below the "
+                                                         "profiles/r01r_pmc_bench_kernels.json, scaled to this run's launches); below the "
                                                          "algorithmic bytes because the transforms are fused",
                      "algorithmic_bytes_per_launch": ntt_bytes / launches if launches else None,
                      "launches": launches, "limb_ntts": limb_polys,
