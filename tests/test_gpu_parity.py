@@ -155,6 +155,32 @@ def test_nntt_2_16_17_many_rows_subblock_walk(logn, rows):
     assert np.array_equal(pad.to_numpy((few.size + 2,))[1:-1].reshape(few.shape), few)
 
 
+@pytest.mark.parametrize("logn", [10, 12, 14])
+def test_nntt_mixed_modulus_sizes(logn):
+    """A ring that mixes a 60-bit q0 / special prime with 40-bit primes (infer.jl:97-112): the 40-bit limbs go through the
+    fp64 kernels and the 60-bit ones through the u64 kernels in two launches over the same rows (ntt_io_t::limb_mask);
+    more rows than compute units, in place and out of place, and the forced-u64 path (variant 2) must agree."""
+    N = 1 << logn
+    qs = H.chain(60, 1, N) + H.chain(40, 3, N) + H.chain(61, 1, N)
+    rows = 2 * 256 // len(qs) + 3 if logn == 14 else 7
+    rng = np.random.default_rng(logn)
+    a = H.rand_residues(rng, qs, (rows,), N)
+    a[0, :, 0] = np.array(qs, dtype=np.uint64) - 1
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    want = ref.nntt(a)
+    for variant in (0, 2):
+        ctx.set_ntt_variant(variant)
+        assert np.array_equal(run_ntt(ctx, a), want), variant
+        assert np.array_equal(run_ntt(ctx, want, inverse=True), a), variant
+    ctx.set_ntt_variant(0)
+    d_in, d_out = dev(a), tf.DeviceBuffer(a.size)
+    ctx.nntt(d_in.ptr, d_out.ptr, rows, len(qs))
+    assert np.array_equal(d_out.to_numpy(a.shape), want)
+    sub = [3, 0, 2]                                   # a selection in another order, still mixed
+    b = H.rand_residues(rng, [qs[i] for i in sub], (5,), N)
+    assert np.array_equal(run_ntt(ctx, b, idx=sub), ref.nntt(b, sub))
+
+
 def test_nntt_limb_selection_and_explicit_psi():
     N = 2048
     q, psi = 1152921504606830593, 811032584449645127    # cryptparams.jl:25

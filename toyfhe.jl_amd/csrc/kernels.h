@@ -131,6 +131,7 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_block(con
             lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
             lift = &lf;
         }
+        if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         if (!first) __syncthreads();  // the previous item's last pass has read LDS
         first = false;
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restri
             j = w % (u32)sel.n;
             if (w < io.add_rows) addend = io.addend + (size_t)(g * io.add_gstride + w) * ntot;
         }
+        if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         if (!first) __syncthreads();
         first = false;

@@ -264,6 +264,8 @@ struct ntt_io_t {
     u32 add_rows;     // mode 2: rows w < add_rows of each group have an addend ...
     u32 add_gstride;  //         ... at addend row g*add_gstride + w
     const u64* addend;
+    u32 limb_mask;    // != 0: only the items whose limb position (index into the selection) has its bit set -- rings that mix
+                      // fp64-size and larger moduli are transformed by two launches, one per arithmetic policy
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -156,7 +156,7 @@ int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const 
         }
     }
     if constexpr (std::is_same<A, ArithFp>::value && LOGB == 14 && IOMODE == 0) {
-        if (x == 0 && c->variant == 0) {  // next row prefetched into registers under the middle pass: +6 % stand-alone, neutral inside the BFV pipeline
+        if (x == 0 && c->variant == 0 && io.limb_mask == 0) {  // next row prefetched into registers under the middle pass: +6 % stand-alone, neutral inside the BFV pipeline
             auto pkern = k_ntt_fwd_pf<A, LOGB, LOGT>;
             static bool pattr_set = false;
             if (!pattr_set) { int rc = set_lds(pkern, lds); if (rc) return rc; pattr_set = true; }
@@ -190,7 +190,7 @@ int launch_block_inv(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const 
     const size_t lds = (size_t)lds_words<LOGB, LOGT>() * 8;
     if constexpr (std::is_same<A, ArithFp>::value && LOGB == 14) {
         // whole 2^14 rows in fp64: the staged kernel (next row copied HBM -> LDS under the last pass)
-        if (x == 0 && c->variant != 3) {
+        if (x == 0 && c->variant != 3 && io.limb_mask == 0) {
             auto skern = k_ntt_inv_staged<A, LOGB, LOGT, IOMODE>;
             static bool sattr_set = false;
             if (!sattr_set) { int rc = set_lds(skern, lds); if (rc) return rc; sattr_set = true; }
@@ -272,6 +272,28 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
     if (!use_block) return launch_generic(c, inverse, src, dst, rows, sel, io);
     if (n <= 14) {
         const bool fp = sel_fp(c, sel, 0);
+        // a ring that mixes fp64-size moduli with larger ones (60-bit q0 / special prime next to 40-bit primes): one launch
+        // per policy, each taking its limbs (ntt_io_t::limb_mask); the digit-lift mode reads source limbs of either size and
+        // stays on the u64 kernels
+        u32 fpmask = 0;
+        for (int j = 0; j < sel.n; j++)
+            if (c->limbs_host[sel.idx[j]].Wd) fpmask |= 1u << j;
+        const u32 all = sel.n >= 32 ? ~0u : ((1u << sel.n) - 1u);
+        if (!fp && c->variant == 0 && fpmask != 0 && fpmask != all && io.mode != 1) {
+            ntt_io_t a = io, b = io;
+            a.limb_mask = fpmask;
+            b.limb_mask = all & ~fpmask;
+            switch (n) {
+#define CASE_(LB)                                                                                                  \
+    case LB: {                                                                                                     \
+        int rc1 = inverse ? launch_block_inv<ArithFp, LB>(c, src, dst, rows, sel, 0, a) : launch_block_fwd<ArithFp, LB>(c, src, dst, rows, sel, 0, a); \
+        if (rc1) return rc1;                                                                                       \
+        return inverse ? launch_block_inv<ArithInt, LB>(c, src, dst, rows, sel, 0, b) : launch_block_fwd<ArithInt, LB>(c, src, dst, rows, sel, 0, b); \
+    }
+                CASE_(10) CASE_(11) CASE_(12) CASE_(13) CASE_(14)
+#undef CASE_
+            }
+        }
         switch (n) {
 #define CASE_(LB)                                                                                                  \
     case LB:                                                                                                       \
