@@ -155,14 +155,15 @@ def test_nntt_2_16_17_many_rows_subblock_walk(logn, rows):
     assert np.array_equal(pad.to_numpy((few.size + 2,))[1:-1].reshape(few.shape), few)
 
 
-@pytest.mark.parametrize("logn", [10, 12, 14])
+@pytest.mark.parametrize("logn", [10, 12, 14, 15, 16, 17])
 def test_nntt_mixed_modulus_sizes(logn):
     """A ring that mixes a 60-bit q0 / special prime with 40-bit primes (infer.jl:97-112): the 40-bit limbs go through the
-    fp64 kernels and the 60-bit ones through the u64 kernels in two launches over the same rows (ntt_io_t::limb_mask);
+    fp64 kernels and the 60-bit ones through the u64 kernels in two passes over the same rows (ntt_io_t::limb_mask; N > 2^14:
+    every kernel of a pass, top stages included, skips the other policy's limbs);
     more rows than compute units, in place and out of place, and the forced-u64 path (variant 2) must agree."""
     N = 1 << logn
     qs = H.chain(60, 1, N) + H.chain(40, 3, N) + H.chain(61, 1, N)
-    rows = 2 * 256 // len(qs) + 3 if logn == 14 else 7
+    rows = max(2 * 256 // len(qs) + 3 if logn in (14, 15, 16) else 7, (1 << 20) // (len(qs) * N) + 1)   # enough words for the two-pass mode
     rng = np.random.default_rng(logn)
     a = H.rand_residues(rng, qs, (rows,), N)
     a[0, :, 0] = np.array(qs, dtype=np.uint64) - 1
@@ -177,7 +178,7 @@ def test_nntt_mixed_modulus_sizes(logn):
     ctx.nntt(d_in.ptr, d_out.ptr, rows, len(qs))
     assert np.array_equal(d_out.to_numpy(a.shape), want)
     sub = [3, 0, 2]                                   # a selection in another order, still mixed
-    b = H.rand_residues(rng, [qs[i] for i in sub], (5,), N)
+    b = H.rand_residues(rng, [qs[i] for i in sub], (max(5, (1 << 20) // (3 * N) + 1),), N)
     assert np.array_equal(run_ntt(ctx, b, idx=sub), ref.nntt(b, sub))
 
 

@@ -501,6 +501,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
     bool first = true;
     for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
         u32 srow = item, j = item % (u32)sel.n;
+        if (!LIFT && io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
         lift_t lf;
         if constexpr (LIFT) {
             const u32 per_ct = io.level * io.nw, b = item / per_ct, rem = item % per_ct, i = rem / io.nw;
@@ -557,7 +558,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
 }
 template <class A, int LOGB, int LOGT>
 __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_pair(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems) {
+                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems,
+                                                             u32 limb_mask) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     constexpr int K1 = pass_k_inv(LOGB, LOGT, LOGB), S1 = LOGB - K1;
     typedef pgeom<LOGB, LOGT, S1, K1> G1;
@@ -567,6 +569,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_pair(const u64* __restric
     const u32 tid = threadIdx.x;
     bool first = true;
     for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        if (limb_mask && !((limb_mask >> (item % (u32)sel.n)) & 1u)) continue;
         const typename A::ctx C = A::make(LT[sel.idx[item % (u32)sel.n]]);
         const u64* s = src + ((size_t)item << (LOGB + 1));
         u64* d = dst + ((size_t)item << (LOGB + 1));
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_pair(const u64* __restric
 template <class A, int LOGB, int LOGT>
 __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_subpair(const u64* __restrict__ src, u64* __restrict__ dst,
                                                                 const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
-                                                                u32 nitems) {
+                                                                u32 nitems, u32 limb_mask) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
     static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass schedule expected");
@@ -633,6 +636,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_subpair(const u64* __rest
         const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x - 1, nitems);
         if (item == ~0u) continue;
         const u32 ph = item & hmask, pl = item >> (x - 1);
+        if (limb_mask && !((limb_mask >> (pl % (u32)sel.n)) & 1u)) continue;
         const typename A::ctx C = A::make(LT[sel.idx[pl % (u32)sel.n]]);
         u64* d = dst + pl * ntot + brev_bits(ph, x);  // even word offset: 16-byte aligned pieces
         u64 held[E];
@@ -699,6 +703,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
         if (item == ~0u) continue;
         const u32 ph = item & 1u, pl = item >> 1;
         u32 srow = pl, j = pl % (u32)sel.n;
+        if (!LIFT && io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;
         lift_t lf;
         if constexpr (LIFT) {
             const u32 per_ct = io.level * io.nw, b = pl / per_ct, rem = pl % per_ct, i = rem / io.nw;
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
 template <class A, int LOGB, int LOGT>
 __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_subpair(const u64* __restrict__ src, u64* __restrict__ dst,
                                                                 const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
-                                                                u32 nitems) {
+                                                                u32 nitems, u32 limb_mask) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     constexpr int K1 = pass_k_inv(LOGB, LOGT, LOGB), S1 = LOGB - K1;
     typedef pgeom<LOGB, LOGT, S1, K1> G1;
@@ -805,6 +810,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_subpair(const u64* __rest
         const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x - 1, nitems);
         if (item == ~0u) continue;
         const u32 ph = item & hmask, pl = item >> (x - 1);
+        if (limb_mask && !((limb_mask >> (pl % (u32)sel.n)) & 1u)) continue;
         const typename A::ctx C = A::make(LT[sel.idx[pl % (u32)sel.n]]);
         const u64* s = src + pl * ntot + brev_bits(ph, x);
         u64 raw[2][E];
@@ -847,20 +853,22 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_subpair(const u64* __rest
 // top stages of N > 2^LOGB transforms: one column per thread, rows = count*limbs
 template <int X>
 __global__ __launch_bounds__(256) void k_ntt_fwd_top(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                      const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int logn) {
+                                                      const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int logn, u32 limb_mask) {
     const u64 stride = (u64)1 << (logn - X);
     const u32 chunks = (u32)((stride + 255) / 256);
     const u32 row = blockIdx.x / chunks;
+    if (limb_mask && !((limb_mask >> (row % (u32)sel.n)) & 1u)) return;  // ntt_io_t::limb_mask
     const ntt_limb_t L = LT[sel.idx[row % (u32)sel.n]];
     const u64 col = (u64)(blockIdx.x % chunks) * blockDim.x + threadIdx.x;
     if (col < stride) ntt_fwd_top<X>(src + ((size_t)row << logn), dst + ((size_t)row << logn), L.W, L.q, col, stride);
 }
 template <int X>
 __global__ __launch_bounds__(256) void k_ntt_inv_top(const u64* __restrict__ src, u64* __restrict__ dst,
-                                                      const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int logn) {
+                                                      const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int logn, u32 limb_mask) {
     const u64 stride = (u64)1 << (logn - X);
     const u32 chunks = (u32)((stride + 255) / 256);
     const u32 row = blockIdx.x / chunks;
+    if (limb_mask && !((limb_mask >> (row % (u32)sel.n)) & 1u)) return;  // ntt_io_t::limb_mask
     const ntt_limb_t L = LT[sel.idx[row % (u32)sel.n]];
     const u64 col = (u64)(blockIdx.x % chunks) * blockDim.x + threadIdx.x;
     if (col < stride) ntt_inv_top<X>(src + ((size_t)row << logn), dst + ((size_t)row << logn), L, col, stride);

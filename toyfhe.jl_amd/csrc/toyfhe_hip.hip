@@ -131,6 +131,9 @@ bool sel_fp(const tfhe_ctx* c, const limb_sel_t& sel, int x) {
 }
 
 ntt_io_t io_plain() { ntt_io_t io; memset(&io, 0, sizeof io); return io; }
+// a ring of mixed modulus sizes is split into one pass per arithmetic policy only when there is enough work to pay for the
+// second set of launches (a single ciphertext at N = 2^16 is 0.9 M words and stays on the u64 kernels)
+#define TFHE_MIXED_MIN_WORDS (1ll << 20)
 
 template <class A, int LOGB, int IOMODE = 0>
 int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x, const ntt_io_t& io) {
@@ -218,7 +221,7 @@ int launch_block_inv(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const 
 
 // sub-blocks of N >= 2^16 rows, two per workgroup (k_ntt_*_subpair); plain I/O, 16-byte aligned rows
 template <class A>
-int launch_subpair(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x) {
+int launch_subpair(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x, u32 mask) {
     constexpr int LOGB = 14, LOGT = logt_for(LOGB);
     const size_t lds = (size_t)lds_words<LOGB, LOGT>() * 8;
     auto fk = k_ntt_fwd_subpair<A, LOGB, LOGT>;
@@ -233,8 +236,8 @@ int launch_subpair(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t 
     const unsigned items = (unsigned)(rows << (x - 1));
     const unsigned grid = std::min(items, (unsigned)c->num_cus);
     prof_begin(c, rows);
-    if (inverse) hipLaunchKernelGGL(ik, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items);
-    else hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items);
+    if (inverse) hipLaunchKernelGGL(ik, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items, mask);
+    else hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, x, items, mask);
     prof_end(c);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
@@ -261,51 +264,13 @@ int launch_generic(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t 
     return TFHE_OK;
 }
 
-// forward / inverse transform of `rows` limb-polynomials; src == dst allowed
-// `io` (optional) selects the fused global-I/O transforms of ntt_io_t; only for N <= 2^14 (single-block transforms)
-int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, const ntt_io_t* iop = nullptr) {
-    if (rows == 0) return TFHE_OK;
-    const ntt_io_t io = iop ? *iop : io_plain();
-    if (rows < 0 || (rows << std::max(0, c->logN - 14)) > 0x7fffffffll) return fail(TFHE_E_BADARG, "bad polynomial count");
-    const int n = c->logN;
-    const bool use_block = (c->variant != 1 && n >= 10) || n > 14;
-    if (!use_block) return launch_generic(c, inverse, src, dst, rows, sel, io);
-    if (n <= 14) {
-        const bool fp = sel_fp(c, sel, 0);
-        // a ring that mixes fp64-size moduli with larger ones (60-bit q0 / special prime next to 40-bit primes): one launch
-        // per policy, each taking its limbs (ntt_io_t::limb_mask); the digit-lift mode reads source limbs of either size and
-        // stays on the u64 kernels
-        u32 fpmask = 0;
-        for (int j = 0; j < sel.n; j++)
-            if (c->limbs_host[sel.idx[j]].Wd) fpmask |= 1u << j;
-        const u32 all = sel.n >= 32 ? ~0u : ((1u << sel.n) - 1u);
-        if (!fp && c->variant == 0 && fpmask != 0 && fpmask != all && io.mode != 1) {
-            ntt_io_t a = io, b = io;
-            a.limb_mask = fpmask;
-            b.limb_mask = all & ~fpmask;
-            switch (n) {
-#define CASE_(LB)                                                                                                  \
-    case LB: {                                                                                                     \
-        int rc1 = inverse ? launch_block_inv<ArithFp, LB>(c, src, dst, rows, sel, 0, a) : launch_block_fwd<ArithFp, LB>(c, src, dst, rows, sel, 0, a); \
-        if (rc1) return rc1;                                                                                       \
-        return inverse ? launch_block_inv<ArithInt, LB>(c, src, dst, rows, sel, 0, b) : launch_block_fwd<ArithInt, LB>(c, src, dst, rows, sel, 0, b); \
-    }
-                CASE_(10) CASE_(11) CASE_(12) CASE_(13) CASE_(14)
-#undef CASE_
-            }
-        }
-        switch (n) {
-#define CASE_(LB)                                                                                                  \
-    case LB:                                                                                                       \
-        if (fp) return inverse ? launch_block_inv<ArithFp, LB>(c, src, dst, rows, sel, 0, io) : launch_block_fwd<ArithFp, LB>(c, src, dst, rows, sel, 0, io); \
-        return inverse ? launch_block_inv<ArithInt, LB>(c, src, dst, rows, sel, 0, io) : launch_block_fwd<ArithInt, LB>(c, src, dst, rows, sel, 0, io);
-            CASE_(10) CASE_(11) CASE_(12) CASE_(13) CASE_(14)
-#undef CASE_
-        }
-    }
-    // N > 2^14: x top stages on global memory + 2^14 blocks; needs an out-of-place intermediate
-    const int x = n - 14;
-    const bool pair15 = x == 1 && c->variant == 0 && sel_fp(c, sel, 1);
+// N > 2^14 with one arithmetic policy (`fp`) for the block stage: x top stages on global memory + 2^14 blocks (needs an
+// out-of-place intermediate), or the one-kernel variants of the fp64 policy.  io.limb_mask restricts every kernel of the
+// call to those limbs (rings that mix modulus sizes: one call per policy).
+int run_ntt_large(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, const ntt_io_t& io,
+                  const ntt_io_t* iop, bool fp) {
+    const int n = c->logN, x = n - 14;
+    const bool pair15 = x == 1 && c->variant == 0 && fp;
     if (iop && x == 1 && !(pair15 && !inverse && io.mode == 1))
         return fail(TFHE_E_UNSUPPORTED, "fused NTT I/O transforms need N <= 2^14 (digit lift: N <= 2^16, fp64 policy)");
     if (pair15) {
@@ -322,7 +287,7 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
         }
         const unsigned grid = std::min((unsigned)rows, (unsigned)c->num_cus);
         prof_begin(c, rows);
-        if (inverse) hipLaunchKernelGGL((k_ntt_inv_pair<ArithFp, 14, LOGT>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows);
+        if (inverse) hipLaunchKernelGGL((k_ntt_inv_pair<ArithFp, 14, LOGT>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows, io.limb_mask);
         else if (io.mode == 1) hipLaunchKernelGGL((k_ntt_fwd_pair<ArithFp, 14, LOGT, true>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows, io);
         else hipLaunchKernelGGL((k_ntt_fwd_pair<ArithFp, 14, LOGT>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows, io);
         prof_end(c);
@@ -331,7 +296,7 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
     }
     if (x > 3) return fail(TFHE_E_UNSUPPORTED, "N = 2^%d not supported (max 2^17)", n);
     // fp64 policy: two sub-blocks per workgroup (16-byte pieces on the natural-order side)
-    const bool pairable = x >= 2 && c->variant == 0 && sel_fp(c, sel, x) && (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0;
+    const bool pairable = x >= 2 && c->variant == 0 && fp && (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0;
     if (iop && !(pairable && x == 2 && !inverse && io.mode == 1 && src != dst))
         return fail(TFHE_E_UNSUPPORTED, "fused NTT I/O transforms need N <= 2^14 (digit lift: N <= 2^16, fp64 policy)");
     if (!inverse && pairable && x == 2 && src != dst) {
@@ -363,28 +328,89 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
     if (!inverse) {
         prof_begin(c, 0);
         switch (x) {
-            case 1: hipLaunchKernelGGL(k_ntt_fwd_top<1>, tg, dim3(256), 0, c->stream, src, t, c->limbs_dev, sel, n); break;
-            case 2: hipLaunchKernelGGL(k_ntt_fwd_top<2>, tg, dim3(256), 0, c->stream, src, t, c->limbs_dev, sel, n); break;
-            default: hipLaunchKernelGGL(k_ntt_fwd_top<3>, tg, dim3(256), 0, c->stream, src, t, c->limbs_dev, sel, n); break;
+            case 1: hipLaunchKernelGGL(k_ntt_fwd_top<1>, tg, dim3(256), 0, c->stream, src, t, c->limbs_dev, sel, n, io.limb_mask); break;
+            case 2: hipLaunchKernelGGL(k_ntt_fwd_top<2>, tg, dim3(256), 0, c->stream, src, t, c->limbs_dev, sel, n, io.limb_mask); break;
+            default: hipLaunchKernelGGL(k_ntt_fwd_top<3>, tg, dim3(256), 0, c->stream, src, t, c->limbs_dev, sel, n, io.limb_mask); break;
         }
         prof_end(c);
         HIP_TRY(hipGetLastError());
-        if (pairable) return launch_subpair<ArithFp>(c, false, t, dst, rows, sel, x);
-        return sel_fp(c, sel, x) ? launch_block_fwd<ArithFp, 14>(c, t, dst, rows, sel, x, io) : launch_block_fwd<ArithInt, 14>(c, t, dst, rows, sel, x, io);
+        if (pairable) return launch_subpair<ArithFp>(c, false, t, dst, rows, sel, x, io.limb_mask);
+        return fp ? launch_block_fwd<ArithFp, 14>(c, t, dst, rows, sel, x, io) : launch_block_fwd<ArithInt, 14>(c, t, dst, rows, sel, x, io);
     }
-    if (pairable) rc = launch_subpair<ArithFp>(c, true, src, t, rows, sel, x);
-    else rc = sel_fp(c, sel, x) ? launch_block_inv<ArithFp, 14>(c, src, t, rows, sel, x, io) : launch_block_inv<ArithInt, 14>(c, src, t, rows, sel, x, io);
+    if (pairable) rc = launch_subpair<ArithFp>(c, true, src, t, rows, sel, x, io.limb_mask);
+    else rc = fp ? launch_block_inv<ArithFp, 14>(c, src, t, rows, sel, x, io) : launch_block_inv<ArithInt, 14>(c, src, t, rows, sel, x, io);
     if (rc) return rc;
     prof_begin(c, 0);
     switch (x) {
-        case 1: hipLaunchKernelGGL(k_ntt_inv_top<1>, tg, dim3(256), 0, c->stream, t, dst, c->limbs_dev, sel, n); break;
-        case 2: hipLaunchKernelGGL(k_ntt_inv_top<2>, tg, dim3(256), 0, c->stream, t, dst, c->limbs_dev, sel, n); break;
-        default: hipLaunchKernelGGL(k_ntt_inv_top<3>, tg, dim3(256), 0, c->stream, t, dst, c->limbs_dev, sel, n); break;
+        case 1: hipLaunchKernelGGL(k_ntt_inv_top<1>, tg, dim3(256), 0, c->stream, t, dst, c->limbs_dev, sel, n, io.limb_mask); break;
+        case 2: hipLaunchKernelGGL(k_ntt_inv_top<2>, tg, dim3(256), 0, c->stream, t, dst, c->limbs_dev, sel, n, io.limb_mask); break;
+        default: hipLaunchKernelGGL(k_ntt_inv_top<3>, tg, dim3(256), 0, c->stream, t, dst, c->limbs_dev, sel, n, io.limb_mask); break;
     }
     prof_end(c);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
+
+// forward / inverse transform of `rows` limb-polynomials; src == dst allowed
+// `io` (optional) selects the fused global-I/O transforms of ntt_io_t; only for N <= 2^14 (single-block transforms)
+int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, const ntt_io_t* iop = nullptr) {
+    if (rows == 0) return TFHE_OK;
+    const ntt_io_t io = iop ? *iop : io_plain();
+    if (rows < 0 || (rows << std::max(0, c->logN - 14)) > 0x7fffffffll) return fail(TFHE_E_BADARG, "bad polynomial count");
+    const int n = c->logN;
+    const bool use_block = (c->variant != 1 && n >= 10) || n > 14;
+    if (!use_block) return launch_generic(c, inverse, src, dst, rows, sel, io);
+    if (n <= 14) {
+        const bool fp = sel_fp(c, sel, 0);
+        // a ring that mixes fp64-size moduli with larger ones (60-bit q0 / special prime next to 40-bit primes): one launch
+        // per policy, each taking its limbs (ntt_io_t::limb_mask); the digit-lift mode reads source limbs of either size and
+        // stays on the u64 kernels
+        u32 fpmask = 0;
+        for (int j = 0; j < sel.n; j++)
+            if (c->limbs_host[sel.idx[j]].Wd) fpmask |= 1u << j;
+        const u32 all = sel.n >= 32 ? ~0u : ((1u << sel.n) - 1u);
+        if (!fp && c->variant == 0 && fpmask != 0 && fpmask != all && io.mode != 1 && (rows << n) >= TFHE_MIXED_MIN_WORDS) {
+            ntt_io_t a = io, b = io;
+            a.limb_mask = fpmask;
+            b.limb_mask = all & ~fpmask;
+            switch (n) {
+#define CASE_(LB)                                                                                                  \
+    case LB: {                                                                                                     \
+        int rc1 = inverse ? launch_block_inv<ArithFp, LB>(c, src, dst, rows, sel, 0, a) : launch_block_fwd<ArithFp, LB>(c, src, dst, rows, sel, 0, a); \
+        if (rc1) return rc1;                                                                                       \
+        return inverse ? launch_block_inv<ArithInt, LB>(c, src, dst, rows, sel, 0, b) : launch_block_fwd<ArithInt, LB>(c, src, dst, rows, sel, 0, b); \
+    }
+                CASE_(10) CASE_(11) CASE_(12) CASE_(13) CASE_(14)
+#undef CASE_
+            }
+        }
+        switch (n) {
+#define CASE_(LB)                                                                                                  \
+    case LB:                                                                                                       \
+        if (fp) return inverse ? launch_block_inv<ArithFp, LB>(c, src, dst, rows, sel, 0, io) : launch_block_fwd<ArithFp, LB>(c, src, dst, rows, sel, 0, io); \
+        return inverse ? launch_block_inv<ArithInt, LB>(c, src, dst, rows, sel, 0, io) : launch_block_fwd<ArithInt, LB>(c, src, dst, rows, sel, 0, io);
+            CASE_(10) CASE_(11) CASE_(12) CASE_(13) CASE_(14)
+#undef CASE_
+        }
+    }
+    // N > 2^14
+    if (!iop && c->variant == 0) {
+        u32 fpmask = 0;
+        for (int j = 0; j < sel.n; j++)
+            if (c->limbs_host[sel.idx[j]].Wd) fpmask |= 1u << j;
+        const u32 all = sel.n >= 32 ? ~0u : ((1u << sel.n) - 1u);
+        if (fpmask != 0 && fpmask != all && (rows << n) >= TFHE_MIXED_MIN_WORDS) {  // mixed modulus sizes: one pass per policy, each over its limbs
+            ntt_io_t a = io, b = io;
+            a.limb_mask = fpmask;
+            b.limb_mask = all & ~fpmask;
+            int rc1 = run_ntt_large(c, inverse, src, dst, rows, sel, a, nullptr, true);
+            if (rc1) return rc1;
+            return run_ntt_large(c, inverse, src, dst, rows, sel, b, nullptr, false);
+        }
+    }
+    return run_ntt_large(c, inverse, src, dst, rows, sel, io, iop, sel_fp(c, sel, n - 14));
+}
+
 
 bool bfv_core_fusable(const tfhe_ctx* c, const limb_sel_t& sel) { return c->variant == 0 && c->logN == 14 && sel_fp(c, sel, 0); }
 // forward transforms + tensor + inverse transforms of one BFV multiplication chunk in one kernel (fp64 policy, N = 2^14);
@@ -749,7 +775,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         prof_end(c);
         HIP_TRY(hipGetLastError());
         const dim3 tg((unsigned)((((n >> x) + 255) / 256) * (batch * 2 * nw)));
-        hipLaunchKernelGGL(k_ntt_inv_top<1>, tg, dim3(256), 0, c->stream, dig, special ? S : out, c->limbs_dev, A.w, c->logN);
+        hipLaunchKernelGGL(k_ntt_inv_top<1>, tg, dim3(256), 0, c->stream, dig, special ? S : out, c->limbs_dev, A.w, c->logN, 0u);
         HIP_TRY(hipGetLastError());
         if (special) {
             rescale_arg_t ra;
