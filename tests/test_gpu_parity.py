@@ -319,6 +319,27 @@ def test_keyswitch_matches_oracle(N, bits, Lk, special):
         ctx.keyswitch(Lk, Lk + 1, special, devk.ptr, Lk, devk.ptr, 2, devk.ptr, 1)  # level outside the key ring
 
 
+@pytest.mark.parametrize("special", [True, False])
+def test_keyswitch_mixed_modulus_sizes(special):
+    """Key switch on a ring that mixes a 60-bit q0 with 40-bit primes (+ a 61-bit special prime): the digit lift stays on
+    the u64 kernels, the inverse transforms (addend mode) run as one pass per arithmetic policy; batch large enough for
+    the two-pass mode."""
+    N, batch = 1 << 12, 48
+    qs = H.chain(60, 1, N) + H.chain(40, 2, N) + H.chain(61, 1, N)
+    Lk = len(qs)
+    level = Lk - 1 if special else Lk
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(7 + special)
+    evk = H.uniform_evk(rng, qs, Lk, N)
+    ct = H.rand_residues(rng, qs[:level], (batch, 2), N)
+    devk, dct, dout = dev(evk), dev(ct), tf.DeviceBuffer(batch * 2 * level * N)
+    want = ref.keyswitch(level, special, evk, ct)
+    for variant in (0, 2):
+        ctx.set_ntt_variant(variant)
+        ctx.keyswitch(Lk, level, special, devk.ptr, Lk, dct.ptr, 2, dout.ptr, batch)
+        assert np.array_equal(dout.to_numpy(want.shape), want), variant
+
+
 @pytest.mark.parametrize("N,bits,L,w", [(32, 60, 1, 1), (64, 50, 1, 8), (32, 40, 2, 10), (2048, 50, 3, 16), (16, 61, 4, 32),
                                         (1 << 15, 50, 1, 20)])
 def test_keyswitch_window_matches_oracle(N, bits, L, w):
