@@ -1505,9 +1505,9 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
         u64* const t1 = T + (((size_t)(b * 3 + 1) * nb + j) << LOGB);
         u64* const t2 = T + (((size_t)(b * 3 + 2) * nb + j) << LOGB);
         typename A::elem A0[E], A1[E], v[E];
-        // range (fp64arith.h): the held transforms are reduced to |A| <= p/2; the running one stays lazy (|v| <= 5.7 p after the
-        // 4-stage last pass), so |A v| / p <= 2.85 p < 2^52 and a product is exact with |r| <= (1/2 + 1.5 a 2.85) p = 1.7 p;
-        // a0 b1 + a1 b0 <= 2.7 p; fused_inv_from_regs reduces before the inverse butterflies
+        // range (fp64arith.h): the held transforms are reduced to |A| <= p/2; the running one stays lazy (|v| <= 7.68 p at the end
+        // of the forward plan), so |A v| / p <= 3.84 p and a product is exact with |r| <= (1/2 + 1.5 a 3.84) p = 1.94 p;
+        // a0 b1 + a1 b0 <= 3.9 p < 7.9 p; fused_inv_from_regs reduces before the inverse butterflies
         const u64 *pa0 = Ea + r0, *pa1 = Ea + r1, *pb0 = Eb + r0, *pb1 = Eb + r1;
         if (alt.a && alt.idx[j] >= 0) {
             const size_t s0 = ((size_t)(b * 2 + 0) * alt.ns + alt.idx[j]) << LOGB, s1 = ((size_t)(b * 2 + 1) * alt.ns + alt.idx[j]) << LOGB;
