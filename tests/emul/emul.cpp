@@ -214,3 +214,12 @@ extern "C" void emul_ckks_round(const double* x, long count, uint64_t smant, int
 extern "C" double emul_ckks_to_double(const uint64_t* w, int nwords, int neg, uint64_t smant, int sexp) {
     return ckks_words_to_double(w, nwords, neg != 0, smant, sexp);
 }
+
+// bfv_fast.h centred_double_bits: the centred residue as the exact double (the form c2 takes between the BFV contraction
+// and the fused key switch)
+extern "C" double emul_centred_double(uint64_t r, uint64_t q) {
+    const uint64_t bits = centred_double_bits(r, q);
+    double d;
+    memcpy(&d, &bits, 8);
+    return d;
+}

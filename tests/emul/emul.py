@@ -28,6 +28,8 @@ def lib():
         L.emul_ckks_round.restype = None
         L.emul_ckks_to_double.argtypes = [u64p, C.c_int, C.c_int, C.c_uint64, C.c_int]
         L.emul_ckks_to_double.restype = C.c_double
+        L.emul_centred_double.argtypes = [C.c_uint64, C.c_uint64]
+        L.emul_centred_double.restype = C.c_double
         _LIB = L
     return _LIB
 
@@ -104,3 +106,7 @@ def ckks_to_double(mag: int, neg: bool, smant, sexp):
     nwords = max(1, -(-mag.bit_length() // 64))
     w = np.array([(mag >> (64 * i)) & (2**64 - 1) for i in range(nwords)], dtype=np.uint64)
     return lib().emul_ckks_to_double(_p(w), nwords, int(neg), int(smant), int(sexp))
+
+
+def centred_double(r: int, q: int) -> float:
+    return lib().emul_centred_double(int(r), int(q))

@@ -251,3 +251,16 @@ def test_ckks_fixed_point_conversions(smant, sexp):
             assert got_d == float(exact), (mag, neg)
         else:
             assert abs(Fraction(got_d) - exact) <= abs(exact) * Fraction(1, 2**51)
+
+
+@pytest.mark.parametrize("bits", [20, 40, 50])
+def test_centred_double_hand_over(bits):
+    """bfv_fast.h centred_double_bits (c2 between the BFV contraction and the fused key switch): the centred residue
+    r - q (r > q/2) or r, as an exact double -- edges of the centring and random values."""
+    q = _chain(bits, 1, 1 << 10)[0]
+    rng = np.random.default_rng(bits)
+    vals = [0, 1, 2, q // 2 - 1, q // 2, q // 2 + 1, q // 2 + 2, q - 2, q - 1] + [int(v) for v in rng.integers(0, q, size=200)]
+    for r in vals:
+        want = r - q if r > q // 2 else r          # SignedMod-style centred representative (rlwe_she.jl:326-329)
+        got = emul.centred_double(r, q)
+        assert got == float(want) and float(int(got)) == got, (r, q, got, want)
