@@ -601,6 +601,29 @@ def test_fused_pipeline_equals_three_kernel_pipeline():
     assert np.array_equal(outs[(0, 48)][pick], want)
 
 
+@pytest.mark.parametrize("bits_s", [(40, 50), (50, 50)])
+def test_bfv_mul_relin_prelift_condition(bits_s):
+    """tfhe_bfv_mul_relin at N = 2^14 on two-limb rings: with moduli of one size class c2 goes to the fused key switch as
+    centred doubles (bit-cast lift); with a 40-bit next to a 50-bit modulus (q_i > 2 q_j) that hand-over is not taken and
+    the in-kernel lift with its reduction runs.  Both against the oracle."""
+    N, t = 1 << 14, 65537
+    qs = H.chain(bits_s[0], 1, N) + [q for q in H.chain(bits_s[1], 2, N) if q not in H.chain(bits_s[0], 1, N)][:1]
+    ext = [q for q in H.chain(50, 8, N) if q not in qs][:3]
+    ch = qs + ext
+    ctx = tf.Context(N, ch)
+    plan = tf.BfvPlan(ctx, ctx, t, idx_s=[0, 1])
+    rng = np.random.default_rng(sum(bits_s))
+    batch = 3
+    c1, c2 = H.rand_residues(rng, qs, (batch, 2), N), H.rand_residues(rng, qs, (batch, 2), N)
+    evk = H.uniform_evk(rng, qs, 2, N)
+    do = tf.DeviceBuffer(batch * 2 * 2 * N)
+    devk, d1, d2 = dev(evk), dev(c1), dev(c2)                    # keep the buffers alive across the asynchronous call
+    plan.mul_relin(devk.ptr, 2, d1.ptr, d2.ptr, do.ptr, batch)
+    rs, rb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, ch)
+    want = rs.keyswitch(2, False, evk, ref_cpu.bfv_mul(rs, rb, t, c1, c2))
+    assert np.array_equal(do.to_numpy((batch, 2, 2, N)), want)
+
+
 def test_full_size_ntt_properties():
     N, L = 1 << 14, 8
     qs = H.chain(50, L, N)
