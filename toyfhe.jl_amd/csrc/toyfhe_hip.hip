@@ -774,18 +774,14 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, dig, c->limbs_dev, A, Lk, items);
         prof_end(c);
         HIP_TRY(hipGetLastError());
-        const dim3 tg((unsigned)((((n >> x) + 255) / 256) * (batch * 2 * nw)));
-        hipLaunchKernelGGL(k_ntt_inv_top<1>, tg, dim3(256), 0, c->stream, dig, special ? S : out, c->limbs_dev, A.w, c->logN, 0u);
-        HIP_TRY(hipGetLastError());
+        // inverse top stage + "+ c" / special-prime contraction in one pass over the sub-block results
+        rescale_arg_t ra;
+        memset(&ra, 0, sizeof ra);
         if (special) {
-            rescale_arg_t ra;
-            memset(&ra, 0, sizeof ra);
             const u64 P = c->q[Lk - 1];
             for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
-            hipLaunchKernelGGL(k_ks_rescale_add, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
-        } else {
-            hipLaunchKernelGGL(k_ks_add_ct, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, ct, out, c->limbs_dev, A, n, add_s);
         }
+        hipLaunchKernelGGL(k_ks_top_tail, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 2), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
