@@ -1614,17 +1614,20 @@ __global__ __launch_bounds__(256) void k_ks_rescale_add(const u64* __restrict__ 
     }
 }
 
-// Tail of the sub-block fused key switch at N = 2^(LOGB+1) (k_ks_fused_sub): the inverse top stage (it needs both sub-blocks
-// of a row: out_lo = (r0 + r1) N^-1, out_hi = (r0 - r1) W[1]^-1 N^-1, ntt_inv_top<1>) together with what follows it --
-// "+ c" (k_ks_add_ct) or, with the special prime, the ModulusRaised contraction and "+ c" (k_ks_rescale_add) -- coefficient
-// pair by coefficient pair, so the transformed sums are read once and nothing intermediate is written.
-// T: [batch][2][nw][2][N/2] (sub-block results, canonical); out: [batch][2][level][N]; rows = batch*2*level.
+// Tail of a key switch whose sums are held as inverse-transformed sub-blocks (N = 2^(LOGB+X): k_ks_fused_sub at X = 1, the
+// paired sub-block inverse at X = 2): the X inverse top stages (they need all sub-blocks of a row, ntt_inv_top_regs)
+// together with what follows them -- "+ c" (k_ks_add_ct) or, with the special prime, the ModulusRaised contraction and
+// "+ c" (k_ks_rescale_add) -- coefficient group by coefficient group, so the transformed sums are read once and nothing
+// intermediate is written.
+// T: [batch][2][nw][2^X][N >> X] (sub-block results, < 2q); out: [batch][2][level][N]; rows = batch*2*level.
+template <int X>
 __global__ __launch_bounds__(256) void k_ks_top_tail(const u64* __restrict__ T, const u64* __restrict__ ct, u64* __restrict__ out,
                                                       const ntt_limb_t* __restrict__ LT, ks_arg_t A, rescale_arg_t ra, u32 n,
                                                       u32 add_s) {
+    constexpr int R = 1 << X;
     const u32 row = blockIdx.x, j = row % (u32)A.level, s = (row / (u32)A.level) & 1u, b = row / (2u * (u32)A.level);
     const ntt_limb_t L = LT[A.w.idx[j]];
-    const u32 half = n >> 1;
+    const u32 stride = n >> X;
     const u64* tj = T + (((size_t)b * 2 + s) * A.nw + j) * n;
     const u64* c = s < add_s ? ct + (((size_t)b * A.polys + s) * A.level + j) * n : nullptr;
     u64* o = out + (size_t)row * n;
@@ -1632,24 +1635,31 @@ __global__ __launch_bounds__(256) void k_ks_top_tail(const u64* __restrict__ T, 
     if (A.special) {
         const ntt_limb_t LP = LT[A.w.idx[A.level]];
         const u64* tl = T + (((size_t)b * 2 + s) * A.nw + A.level) * n;
-        const u64 P = LP.q;
-        for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < half; k += gridDim.y * blockDim.x) {
-            const u64 v0 = tj[k], v1 = tj[k + half], p0 = tl[k], p1 = tl[k + half];
-            const u64 x0 = csub(shoup_lazy(v0 + v1, L.ninv, q), q), x1 = csub(shoup_lazy(v0 + 2 * q - v1, L.w1inv_ninv, q), q);
-            const u64 y0 = csub(shoup_lazy(p0 + p1, LP.ninv, P), P), y1 = csub(shoup_lazy(p0 + 2 * P - p1, LP.w1inv_ninv, P), P);
-            u64 r0 = shoup_full(submod(x0, barrett_reduce128(y0, 0, L.br), q), ra.qlinv[j], q);
-            u64 r1 = shoup_full(submod(x1, barrett_reduce128(y1, 0, L.br), q), ra.qlinv[j], q);
-            if (c) { r0 = addmod(r0, c[k], q); r1 = addmod(r1, c[k + half], q); }
-            o[k] = r0;
-            o[k + half] = r1;
+        for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < stride; k += gridDim.y * blockDim.x) {
+            u64 v[R], p[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) { v[r] = tj[k + (u32)r * stride]; p[r] = tl[k + (u32)r * stride]; }
+            ntt_inv_top_regs<X>(v, L);
+            ntt_inv_top_regs<X>(p, LP);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                u64 x = shoup_full(submod(v[r], barrett_reduce128(p[r], 0, L.br), q), ra.qlinv[j], q);
+                if (c) x = addmod(x, c[k + (u32)r * stride], q);
+                o[k + (u32)r * stride] = x;
+            }
         }
     } else {
-        for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < half; k += gridDim.y * blockDim.x) {
-            const u64 v0 = tj[k], v1 = tj[k + half];
-            u64 r0 = csub(shoup_lazy(v0 + v1, L.ninv, q), q), r1 = csub(shoup_lazy(v0 + 2 * q - v1, L.w1inv_ninv, q), q);
-            if (c) { r0 = addmod(r0, c[k], q); r1 = addmod(r1, c[k + half], q); }
-            o[k] = r0;
-            o[k + half] = r1;
+        for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < stride; k += gridDim.y * blockDim.x) {
+            u64 v[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) v[r] = tj[k + (u32)r * stride];
+            ntt_inv_top_regs<X>(v, L);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                u64 x = v[r];
+                if (c) x = addmod(x, c[k + (u32)r * stride], q);
+                o[k + (u32)r * stride] = x;
+            }
         }
     }
 }

@@ -596,13 +596,11 @@ TFHE_HD void ntt_fwd_top(const u64* src, u64* dst, const twd_t* W, u64 q, u64 co
     for (int r = 0; r < R; r++) dst[col + (u64)r * stride] = csub(csub(v[r], 2 * q), q);  // canonical: either block policy can take it
 }
 
+// the X top stages of an inverse transform on 2^X values held in registers ([0, 2q) in, canonical out, N^-1 folded in)
 template <int X>
-TFHE_HD void ntt_inv_top(const u64* src, u64* dst, const ntt_limb_t& L, u64 col, u64 stride) {
+TFHE_HD void ntt_inv_top_regs(u64 (&v)[1 << X], const ntt_limb_t& L) {
     constexpr int R = 1 << X;
     const u64 q = L.q;
-    u64 v[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) v[r] = src[col + (u64)r * stride];  // [0,2q)
 #pragma unroll
     for (int d = X - 1; d >= 0; d--) {
         const int half = 1 << (X - 1 - d);
@@ -623,7 +621,17 @@ TFHE_HD void ntt_inv_top(const u64* src, u64* dst, const ntt_limb_t& L, u64 col,
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; r++) dst[col + (u64)r * stride] = csub(v[r], q);
+    for (int r = 0; r < R; r++) v[r] = csub(v[r], q);
+}
+template <int X>
+TFHE_HD void ntt_inv_top(const u64* src, u64* dst, const ntt_limb_t& L, u64 col, u64 stride) {
+    constexpr int R = 1 << X;
+    u64 v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = src[col + (u64)r * stride];  // [0,2q)
+    ntt_inv_top_regs<X>(v, L);
+#pragma unroll
+    for (int r = 0; r < R; r++) dst[col + (u64)r * stride] = v[r];
 }
 
 // ---------------------------------------------------------------------------------------------

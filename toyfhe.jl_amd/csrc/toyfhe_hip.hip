@@ -781,7 +781,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
             const u64 P = c->q[Lk - 1];
             for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
         }
-        hipLaunchKernelGGL(k_ks_top_tail, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 2), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
+        hipLaunchKernelGGL(k_ks_top_tail<1>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 2), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
@@ -812,6 +812,21 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit);
     }
     HIP_TRY(hipGetLastError());
+    if (c->logN == 16 && c->variant == 0 && sel_fp(c, A.w, 2) && level >= 2 && (((uintptr_t)S | (uintptr_t)dig) & 15u) == 0) {
+        // N = 2^16: the paired sub-block inverse into the (now free) digit buffer, then the two inverse top stages together with
+        // the tail (k_ks_top_tail<2>) instead of k_ntt_inv_top<2> + k_ks_rescale_add / k_ks_add_ct
+        rc = launch_subpair<ArithFp>(c, true, S, dig, batch * 2 * nw, A.w, 2, 0u);
+        if (rc) return rc;
+        rescale_arg_t ra;
+        memset(&ra, 0, sizeof ra);
+        if (special) {
+            const u64 P = c->q[Lk - 1];
+            for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+        }
+        hipLaunchKernelGGL(k_ks_top_tail<2>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 4), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
     if (special) {
         rc = run_ntt(c, true, S, S, batch * 2 * nw, A.w);
         if (rc) return rc;
