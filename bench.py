@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric: BFV ciphertext-mul (+ relinearise) per second at N = 2^14, L = 8 RNS
-limbs, batch = 1024 per GPU (configs[1]); NTT GB/s against the HBM roofline from the same timed region.
+limbs, batch = 1024 per GPU (configs[1]); NTT GB/s against the HBM roofline (BASELINE.md #2').
 
 A "step" is one pass of the hot path (tfhe_bfv_mul_relin: exact expand 8->17 limbs; 68 forward limb-NTTs, tensor and
 51 inverse limb-NTTs in one fused kernel; exact scale-and-round back to 8 limbs; RNS-digit key switch with its 64 + 16
-transforms in a second fused kernel) over one batch
-of synthetic ciphertexts already resident in HBM.  One process per GPU; ranks shard the batch (weak
-scaling: the per-GPU batch is fixed), no data-path collective.
+transforms in a second fused kernel) over one batch of synthetic ciphertexts already resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu]
+One process per GPU; ranks shard the batch (weak scaling: the per-GPU batch is fixed), no data-path collective.
+`--gpus N` with N > 1 and no torchrun environment re-executes this script under `python -m torch.distributed.run`
+with N ranks (RCCL); under torchrun the environment's WORLD_SIZE is what runs and what `n_gpus` reports.  After the
+timed region the optional final gather (north_star: "RCCL over xGMI only for the final gather") is timed on its own, so
+the JSON carries the rate without (`value`) and with it (`gather.value_with_gather`).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu] [--no-ntt] [--no-gather]
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,10 +26,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LOGN, L, LBIG, T_PLAIN = 14, 8, 17, 65537
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+N_SIMD, PEAK_CLOCK_HZ = 256 * 4, 2.4e9   # 256 CUs x 4 SIMD16; peak engine clock (78.6 TFLOP/s fp64 vector = 1024 x 16 x 2 x 2.4e9)
+VALU_PEAK_GIPS = N_SIMD * PEAK_CLOCK_HZ / 4 / 1e9   # one wave64 VALU instruction per 4 clocks per SIMD (fp64 is full rate)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_bench_kernels.json")   # regenerated per round by tools/pmc_round.sh
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -31,24 +40,75 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="ciphertext pairs per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="ciphertexts per internal pipeline chunk (0 = default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="ciphertext pairs in the CPU sample (0 = auto)")
-    args = ap.parse_args()
+    ap.add_argument("--no-ntt", action="store_true", help="skip the stand-alone NTT record")
+    ap.add_argument("--no-gather", action="store_true", help="skip the timed final gather (multi-rank runs)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="ciphertext pairs in the all-core CPU sample (0 = auto)")
+    ap.add_argument("--backend", default=os.environ.get("TFHE_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend; 'gloo' + ranks sharing a GPU is a functional check only")
+    return ap.parse_args()
+
+
+def respawn(args):
+    """`python bench.py --gpus N` outside torchrun: become the launcher of N ranks, one per GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def prime_chain(tf, bits, n, N):
+    """first n primes = 1 (mod 2N) above 2^bits (crt.jl:282-295 rule)"""
+    out, p = [], tf.nextprime(2**bits + 1, 1, 2 * N)
+    for _ in range(n):
+        out.append(p)
+        p = tf.nextprime(p + 2 * N, 1, 2 * N)
+    return out
+
+
+def load_pmc():
+    if not os.path.exists(PMC_FILE):
+        return None
+    try:
+        return json.load(open(PMC_FILE))
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn(args))
 
     import numpy as np
     import torch
 
     import toyfhe_jl_amd as tf
-
     from toyfhe_jl_amd import dist as tdist
+
     world, rank, local_rank = tdist.env_world()
-    torch.cuda.set_device(local_rank)
-    tdist.init(backend="nccl", device_id=torch.device("cuda", local_rank))
-    tf.native.check(tf.native.lib().tfhe_set_device(local_rank))
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    if world > ndev and args.backend == "nccl":
+        raise SystemExit(f"{world} ranks but {ndev} visible GPUs (one rank per GPU)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if args.backend == "nccl":
+        tdist.init(backend="nccl", device_id=dev)
+    else:
+        tdist.init(backend=args.backend)
+    coll_dev = dev if args.backend == "nccl" else None
+    tf.native.check(tf.native.lib().tfhe_set_device(dev_index))
 
     N = 1 << LOGN
-    from tests import helpers as H  # prime chain helper only (no oracle compute in the timed path)
-    primes = H.chain(50, LBIG, N)   # first NTT-friendly primes above 2^50 for N = 2^14
+    primes = prime_chain(tf, 50, LBIG, N)
+    assert primes[:2] == [1125899908022273, 1125899908612097]        # BASELINE.md section 3
     qs = primes[:L]
     ctx = tf.Context(N, primes)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -67,44 +127,112 @@ def main():
         return out
 
     c1, c2 = uniform((B, 2)), uniform((B, 2))
+    gen.manual_seed(0xF4E5EED)                                      # the evaluation key is shared by every rank
     evk = uniform((L, 2))
     out = torch.empty((B, 2, L, N), dtype=torch.int64, device=dev)
 
     def step():
         plan.mul_relin(evk.data_ptr(), L, c1.data_ptr(), c2.data_ptr(), out.data_ptr(), B)
 
-    barrier = tdist.barrier
-
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     ctx.prof_enable(True)
-    barrier()
+    tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    barrier()
+    tdist.barrier()
     t1 = time.perf_counter()
     launches, limb_polys, ntt_ms = ctx.prof_read()
     ctx.prof_enable(False)
-    elapsed = t1 - t0
-    elapsed = tdist.max_over_ranks(elapsed, device=dev)
+    elapsed = tdist.max_over_ranks(t1 - t0, device=coll_dev)
 
     total_units = B * world * args.steps
     value = total_units / elapsed
-    ntt_bytes = limb_polys * 2 * N * 8                   # one read + one write per limb transform
-    achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
-    # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs, gfx950 corrections;
-    # tools/pmc_bench.py over this very script at batch 256).  bench.py cannot run the counters itself, so it scales the
-    # committed per-ciphertext figure of the two transform-carrying kernels to this run's launches.
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01r_pmc_bench_kernels.json")
-    if os.path.exists(pmc_path) and launches:
-        pmc = json.load(open(pmc_path))
-        per_ct = sum(k["hbm_bytes_per_launch"] for name, k in pmc["kernels"].items() if "fused" in name) / pmc["batch"]
-        traffic = per_ct * B * args.steps / launches
+
+    # ---- optional final gather (all ranks end up with every result), timed on its own -----------------------------
+    gather = None
+    if world > 1 and not args.no_gather:
+        import torch.distributed as dist
+        flat = out.view(-1)
+        if args.backend == "nccl":
+            full = torch.empty(world * flat.numel(), dtype=flat.dtype, device=dev)
+            run_gather = lambda: dist.all_gather_into_tensor(full, flat)
+        else:
+            run_gather = lambda: tdist.gather_results(out[:8].cpu())    # functional check only
+        run_gather()
+        torch.cuda.synchronize(); tdist.barrier()
+        g0 = time.perf_counter()
+        greps = 3
+        for _ in range(greps):
+            run_gather()
+        torch.cuda.synchronize(); tdist.barrier()
+        g_s = tdist.max_over_ranks((time.perf_counter() - g0) / greps, device=coll_dev)
+        gbytes = flat.numel() * 8 * (world - 1)                        # received per rank
+        gather = {"collective": "all_gather_into_tensor (RCCL over xGMI)" if args.backend == "nccl" else f"{args.backend} functional check",
+                  "ms_per_step": g_s * 1e3, "bytes_received_per_rank": gbytes, "GBs_per_rank": gbytes / g_s / 1e9,
+                  "value_with_gather": B * world / (elapsed / args.steps + g_s)}
+        if args.backend == "nccl":
+            del full
+
+    # ---- roofline of the dominant kernels (k_bfv_core_fused + k_ks_fused) --------------------------------------------
+    # (1) transform-equivalent bytes: SURVEY 8(d)'s unit (one limb transform = 2*N*8 B) x the transforms the launches carry
+    ntt_bytes = limb_polys * 2 * N * 8
+    ntt_s = ntt_ms * 1e-3
+    teq = ntt_bytes / ntt_s / 1e9 if ntt_s > 0 else 0.0
+    # (2) what binds: the fp64 vector ALU.  Wave64 VALU instructions per ciphertext-mul of the two kernels come from the PMC
+    # pass over this very script (SQ_INSTS_VALU, profiles/pmc_bench_kernels.json, tools/pmc_round.sh); bench.py cannot
+    # run counters itself, so it scales the committed per-ciphertext figures to this run's launches and divides by the
+    # HIP-event kernel time measured in this run.
+    pmc = load_pmc()
+    valu_gips = valu_frac = hbm_frac = traffic = clock_ghz = valu_frac_clk = None
+    sq = {}
+    if pmc and launches:
+        fused = {k: v for k, v in pmc["kernels"].items() if "k_bfv_core_fused" in k or "k_ks_fused" in k}
+        cts = B * args.steps                                          # ciphertext-muls carried by this rank's launches
+        per_ct = lambda key: sum(v.get(key, 0.0) / v["launches"] for v in fused.values()) / pmc["batch"]
+        traffic = per_ct("hbm_bytes") * cts / launches
+        hbm_frac = per_ct("hbm_bytes") * cts / ntt_s / (HBM_PEAK_GBS * 1e9)
+        if all("SQ_INSTS_VALU" in v for v in fused.values()):
+            insts = per_ct("SQ_INSTS_VALU") * cts
+            valu_gips = insts / ntt_s / 1e9
+            valu_frac = valu_gips / VALU_PEAK_GIPS
+            gui, dur = per_ct("GRBM_GUI_ACTIVE"), per_ct("duration_ns")
+            if gui and dur:
+                clock_ghz = gui / 8 / dur                             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; shader clock of the profiled pass
+                valu_frac_clk = valu_gips / (N_SIMD * clock_ghz / 4)
+            for k in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                      "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_LDS"):
+                if all(k in v for v in fused.values()):
+                    sq[k + "_per_ctmul"] = per_ct(k)
+    roof = {
+        "bound": "valu-fp64" if valu_frac is not None else "hbm",
+        "kernel": "k_bfv_core_fused + k_ks_fused: the 2^14-point negacyclic NTTs (exact-integer fp64 butterflies) fused with the "
+                  "tensor product / key inner product -- 7 and 10 limb transforms per workgroup item; durations by HIP events "
+                  "around these launches inside the timed region",
+        "achieved": valu_gips if valu_frac is not None else teq,
+        "peak": VALU_PEAK_GIPS if valu_frac is not None else HBM_PEAK_GBS,
+        "unit": "G wave64-VALU-instr/s (1024 SIMDs x 2.4 GHz / 4 clk)" if valu_frac is not None else "GB/s",
+        "frac": valu_frac if valu_frac is not None else teq / HBM_PEAK_GBS,
+        "frac_at_profiled_clock": valu_frac_clk, "profiled_clock_GHz": clock_ghz,
+        "hbm_frac": hbm_frac,
+        "traffic": traffic,
+        "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the two kernels, profiles/pmc_bench_kernels.json, "
+                        "scaled to this run's launches)",
+        "transform_equiv": {"achieved": teq, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": teq / HBM_PEAK_GBS,
+                            "note": "limb transforms x 2*N*8 algorithmic bytes (SURVEY 8d) / kernel time: prices transform throughput, "
+                                    "not HBM utilisation (the fused kernels move fewer bytes than this)"},
+        "algorithmic_bytes_per_launch": ntt_bytes / launches if launches else None,
+        "launches": launches, "limb_ntts": limb_polys,
+        "avg_launch_ms": ntt_ms / launches if launches else None,
+        "ntt_share_of_step": ntt_s / (t1 - t0) if t1 > t0 else None,
+        "counters": sq or None,
+        "pmc_source": (pmc or {}).get("note"),
+    }
+
     result = {
         "metric": "ciphertext-mul/s (BFV ct*ct + relinearize, N=2^14, L=8 RNS)",
         "value": value,
@@ -121,34 +249,66 @@ def main():
         "config": {"workload": "BFV N=2^14, L=8 RNS limbs (50-bit primes), extension basis 17 limbs, t=65537, "
                                "ciphertext-mul + relinearize (RNS-digit keyswitch), bit-exact", "batch_per_gpu": B,
                    "global_batch": B * world, "sharding": f"batch x{world}, no data-path collective"},
-        "roofline": {"bound": "hbm", "kernel": "k_bfv_core_fused + k_ks_fused: the 2^14-point negacyclic NTTs (fp64 butterflies) fused with the "
-                               "tensor product / key inner product -- 7 and 10 limb transforms per workgroup item; units = limb "
-                               "transforms x 2*N*8 algorithmic bytes (SURVEY 8d), durations by HIP events around these launches",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the two kernels, "
-                                                         "profiles/r01r_pmc_bench_kernels.json, scaled to this run's launches); below the "
-                                                         "algorithmic bytes because the transforms are fused",
-                     "algorithmic_bytes_per_launch": ntt_bytes / launches if launches else None,
-                     "launches": launches, "limb_ntts": limb_polys,
-                     "avg_launch_ms": ntt_ms / launches if launches else None,
-                     "ntt_share_of_step": ntt_ms * 1e-3 / elapsed if elapsed > 0 else None},
+        "roofline": roof,
     }
+    if gather is not None:
+        result["gather"] = gather
 
+    # ---- BASELINE.md #2': stand-alone NTT, 4096 polys x 8 limbs, N = 2^14 -------------------------------------------
+    if rank == 0 and not args.no_ntt:
+        polys = 4096
+        rows = polys * L
+        a = torch.randint(0, qs[0], (rows, N), dtype=torch.int64, device=dev, generator=gen)
+        b = torch.empty_like(a)
+        ev = [tf.Event() for _ in range(4)]
+        reps = 10
+        for _ in range(3):
+            ctx.nntt(a.data_ptr(), b.data_ptr(), polys, L)
+            ctx.inntt(b.data_ptr(), a.data_ptr(), polys, L)
+        ev[0].record(ctx)
+        for _ in range(reps):
+            ctx.nntt(a.data_ptr(), b.data_ptr(), polys, L)
+        ev[1].record(ctx)
+        for _ in range(reps):
+            ctx.inntt(b.data_ptr(), a.data_ptr(), polys, L)
+        ev[2].record(ctx)
+        fwd_s, inv_s = ev[0].elapsed_ms(ev[1]) / reps * 1e-3, ev[1].elapsed_ms(ev[2]) / reps * 1e-3
+        gb = rows * N * 8 * 2 / 1e9
+        result["ntt"] = {"workload": f"{polys} polys x {L} limbs, N=2^14, 50-bit primes, out of place (BASELINE.md #2')",
+                         "bytes_per_pass": rows * N * 8 * 2, "fwd_GBs": gb / fwd_s, "inv_GBs": gb / inv_s,
+                         "fwd_frac_of_hbm_peak": gb / fwd_s / HBM_PEAK_GBS, "inv_frac_of_hbm_peak": gb / inv_s / HBM_PEAK_GBS,
+                         "limb_ntts_per_s_fwd": rows / fwd_s, "limb_ntts_per_s_inv": rows / inv_s, "peak_GBs": HBM_PEAK_GBS}
+
+    # ---- CPU baseline: the C restatement of the reference algorithm, 1 thread (the reference is single-threaded) and all cores
     if rank == 0 and world == 1 and not args.no_cpu:
-        from oracle import ref_cpu
-        cores = ref_cpu.lib().ref_num_threads()
-        ns = args.cpu_sample or max(8 * cores, 8)
-        rng = np.random.default_rng(1)
-        s1, s2 = H.rand_residues(rng, qs, (ns, 2), N), H.rand_residues(rng, qs, (ns, 2), N)
-        sk = H.uniform_evk(rng, qs, L, N)
+        from oracle import ref_cpu                                   # checker / baseline only (never on the product path)
+        rl = ref_cpu.lib()
+        cores = rl.ref_num_threads()
         rs, rb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, primes)
-        tc = time.perf_counter()
-        prod = ref_cpu.bfv_mul(rs, rb, T_PLAIN, s1, s2)
-        rs.keyswitch(L, False, sk, prod)
-        tc = time.perf_counter() - tc
-        result["cpu_baseline"] = {"value": ns / tc, "unit": "ciphertext-mul/s", "cores": cores, "kind": "port",
+        rng = np.random.default_rng(1)
+
+        def sample(n):
+            cols = lambda pre: np.stack([rng.integers(0, q, size=tuple(pre) + (N,), dtype=np.uint64) for q in qs], axis=len(pre))
+            return cols((n, 2)), cols((n, 2)), cols((L, 2))
+
+        def run(n):
+            s1, s2, sk = sample(n)
+            tc = time.perf_counter()
+            prod = ref_cpu.bfv_mul(rs, rb, T_PLAIN, s1, s2)
+            rs.keyswitch(L, False, sk, prod)
+            return time.perf_counter() - tc
+
+        ns = args.cpu_sample or max(8 * cores, 8)
+        t_all = run(ns)
+        rl.ref_set_threads(1)
+        n1 = 4
+        t_one = run(n1)
+        rl.ref_set_threads(cores)
+        result["cpu_baseline"] = {"value": ns / t_all, "unit": "ciphertext-mul/s", "cores": cores, "kind": "port",
                                   "sample": f"{ns} ciphertext pairs of the same workload, oracle/ref_cpu.c "
-                                            f"(exact BigInt-style conversions, radix-2 NTT), OpenMP over the batch, {tc:.1f} s"}
+                                            f"(exact BigInt-style conversions, radix-2 NTT), OpenMP over the batch, {t_all:.1f} s",
+                                  "single_thread": {"value": n1 / t_one, "cores": 1,
+                                                    "sample": f"{n1} ciphertext pairs, 1 thread (the reference is single-threaded), {t_one:.1f} s"}}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -19,6 +19,13 @@
  *     caller; NTT-domain data is in natural order: â[k] = a(ψ^(2k+1)) (src/pow2_cyc_rings.jl:278-294).
  *   - all work is enqueued on the context's stream (tfhe_ctx_set_stream); calls are asynchronous
  *     unless stated.  No host pointer is retained after a call returns.
+ *   - threading: a tfhe_ctx (and a tfhe_bfv_plan) carries per-call scratch (transform workspaces, the prepared key rows
+ *     of the fused key switch) that is recycled in stream order, so ONE host thread drives a given context at a time;
+ *     different contexts / plans are independent and may be driven from different threads (no global mutable state
+ *     besides the thread-local error text).  Share read-only inputs (evaluation keys, ciphertexts) freely.
+ *   - a BFV plan over two contexts runs the extension-basis work on ℛbig's stream and the key switch on ℛ's stream and
+ *     orders the two with events; it never re-points a context's stream.  Results are ordered on ℛ's stream
+ *     (tfhe_ctx_sync(small) waits for them).
  */
 #ifndef TOYFHE_HIP_H
 #define TOYFHE_HIP_H
@@ -165,7 +172,7 @@ int tfhe_bfv_mul_relin(tfhe_bfv_plan *plan, const uint64_t *evk, int n_digits, c
 /* expand/contract kernel family: 0 = auto (register-resident constant-folded kernels when ℛbig ⊇ ℛ and the
  * limb counts are instantiated, else the general kernels), 1 = force the general kernels (cross-check). */
 int tfhe_bfv_plan_set_variant(tfhe_bfv_plan *plan, int variant);
-/* ciphertexts processed per internal chunk (workspace = chunk * (7 nb + 3 ns) * N * 8 bytes); 0 = default (128) */
+/* ciphertexts processed per internal chunk (workspace = chunk * (7 nb + 3 ns) * N * 8 bytes); 0 = default (256) */
 int tfhe_bfv_plan_set_chunk(tfhe_bfv_plan *plan, int chunk);
 
 /* ---- measurement hooks (bench.py): HIP events on the ctx stream --------------------------------

@@ -1,0 +1,96 @@
+"""Multi-rank runs of the ENGINE: one process per rank, each running tfhe_bfv_mul_relin on its contiguous
+shard of a global batch, no data-path collective, results gathered at the end and compared with the single-rank run of
+the whole batch and with the oracle.  With >= 2 visible GPUs the ranks take one GPU each and talk RCCL; on a 1-GPU box
+both ranks share GPU 0 and rendezvous over gloo (same engine code path per rank, collective on host tensors)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import toyfhe_jl_amd as tf
+from toyfhe_jl_amd import dist as tdist
+world, rank, local_rank = tdist.env_world()
+ndev = torch.cuda.device_count()
+nccl = ndev >= world
+dev_index = local_rank %% ndev
+torch.cuda.set_device(dev_index)
+dev = torch.device("cuda", dev_index)
+tdist.init(backend="nccl" if nccl else "gloo", **({"device_id": dev} if nccl else {}))
+tf.native.check(tf.native.lib().tfhe_set_device(dev_index))
+N, ns, t, G = 4096, 2, 65537, 7                  # ragged global batch: shards of 4 and 3
+p, ch = tf.nextprime(2**50 + 1, 1, 2 * N), []
+for _ in range(5):
+    ch.append(p); p = tf.nextprime(p + 2 * N, 1, 2 * N)
+qs = ch[:ns]
+rng = np.random.default_rng(0)                   # every rank draws the same global batch and key, owns one shard
+res = lambda pre: np.stack([rng.integers(0, q, size=tuple(pre) + (N,), dtype=np.uint64) for q in qs], axis=len(pre))
+c1, c2, evk = res((G, 2)), res((G, 2)), res((ns, 2))
+ctx = tf.Context(N, ch)
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+plan = tf.BfvPlan(ctx, ctx, t, idx_s=list(range(ns)))
+def run(a, b):
+    n = a.shape[0]
+    da, db, dk = (torch.from_numpy(x.astype(np.int64)).to(dev) for x in (a, b, evk))
+    out = torch.empty((n, 2, ns, N), dtype=torch.int64, device=dev)
+    plan.mul_relin(dk.data_ptr(), ns, da.data_ptr(), db.data_ptr(), out.data_ptr(), n)
+    torch.cuda.synchronize()
+    return out
+start, count = tdist.shard(G, rank, world)
+local = run(c1[start:start + count], c2[start:start + count])
+tdist.barrier()
+parts = tdist.gather_results(local if nccl else local.cpu())
+if rank == 0:
+    full = torch.cat([x.cpu() for x in parts]).numpy().astype(np.uint64)
+    alone = run(c1, c2).cpu().numpy().astype(np.uint64)
+    from oracle import ref_cpu                   # checker
+    rs, rb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, ch)
+    pick = [0, 3, 4, 6]                          # both sides of the shard boundary
+    want = rs.keyswitch(ns, False, evk, ref_cpu.bfv_mul(rs, rb, t, c1[pick], c2[pick]))
+    print(json.dumps({"same_as_single_rank": bool(np.array_equal(full, alone)), "oracle": bool(np.array_equal(full[pick], want)),
+                      "counts": [int(x.shape[0]) for x in parts], "backend": "nccl" if nccl else "gloo", "world": world}))
+torch.distributed.destroy_process_group()
+'''
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_run_the_engine_on_their_shards():
+    script = os.path.join(ROOT, "gpurun_out", "_dist_gpu_worker.py")
+    os.makedirs(os.path.dirname(script), exist_ok=True)
+    open(script, "w").write(WORKER % {"root": ROOT})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script]
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["same_as_single_rank"] and res["oracle"] and res["counts"] == [4, 3] and res["world"] == 2
+
+
+def test_bench_spawns_the_ranks_it_is_asked_for():
+    """`python bench.py --gpus 2` outside torchrun launches two ranks itself and reports n_gpus = 2 with the whole-job
+    rate (one GPU each over RCCL when two are visible; otherwise both on GPU 0 over gloo as a functional check)."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64",
+           "--no-cpu", "--no-ntt", "--backend", backend]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 128 and res["value"] > 0
+    assert res["scaling"] == "weak" and "gather" in res and res["gather"]["value_with_gather"] <= res["value"] * 1.0001

@@ -1297,8 +1297,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
             typename A::elem v[E];
             fused_fwd_to_regs<A, LOGB, LOGT, PRELIFT>(lds, grow, C, first, v, &lf);
             // multiply-accumulate with the key: component 1 (masked) feeds out_0, component 0 (mask) feeds out_1
-            const u64* e_mask = evd + (((size_t)i * 2 + 0) * nw + j << LOGB);    // key words as doubles (k_evk_to_f64)
-            const u64* e_masked = evd + (((size_t)i * 2 + 1) * nw + j << LOGB);
+            const u64* e_mask = evd + ((((size_t)i * 2 + 0) * nw + j) << LOGB);    // key words as doubles (k_evk_to_f64)
+            const u64* e_masked = evd + ((((size_t)i * 2 + 1) * nw + j) << LOGB);
 #pragma unroll
             for (int u = 0; u < G3::SETS; u++) {
                 u32 c0, hi, base;
@@ -1426,8 +1426,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, pre);
             }
             // multiply-accumulate with the key words at natural-order positions 2 nat + sb
-            const u64* e_mask = evd + (((size_t)i * 2 + 0) * nw + j << (LOGB + X)) + brev_bits(sb, X);    // doubles (k_evk_to_f64)
-            const u64* e_masked = evd + (((size_t)i * 2 + 1) * nw + j << (LOGB + X)) + brev_bits(sb, X);
+            const u64* e_mask = evd + ((((size_t)i * 2 + 0) * nw + j) << (LOGB + X)) + brev_bits(sb, X);    // doubles (k_evk_to_f64)
+            const u64* e_masked = evd + ((((size_t)i * 2 + 1) * nw + j) << (LOGB + X)) + brev_bits(sb, X);
 #pragma unroll
             for (int u = 0; u < G3::SETS; u++) {
                 u32 c0, hi, base;
