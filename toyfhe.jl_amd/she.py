@@ -163,7 +163,7 @@ class BGVParams(SHESchemeParams):
         return self.ring(_map_plain(plain, lambda m: int(m) % self.t))
 
     def decode(self, b):
-        Q = self.ring.modulus()
+        Q = b.ring.modulus()                 # the ciphertext's own level (a ModulusRaised / modswitched ring is a sub-basis)
         return _map_plain(b.to_ints(), lambda x: (x - Q if x > Q // 2 else x) % self.t)
 
 
