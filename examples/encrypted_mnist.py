@@ -2,10 +2,11 @@
 """Encrypted CNN inference in the shape of the reference's examples/encrypted_mnist/infer.jl,
 driven through the host mirror with every ring operation on the MI355X.
 
-The reference evaluates a trained Flux model (mnist_conv.bson) on MNIST; neither the weights (BSON, needs Julia) nor
-the dataset are available here, so this script draws a model of the same architecture and a batch of synthetic 28x28
-images from a seeded generator and checks the homomorphic result against the same arithmetic in float64
-(infer.jl:55-88 `do_encrypted_inference`):
+The reference evaluates its trained Flux model (examples/encrypted_mnist/mnist_conv.bson) on MNIST.  The weights are
+exported from that file by tools/export_mnist_bson.py (a BSON reader, run in the build container) into
+tests/golden/mnist_conv.npz and used here by default (`--model synthetic` draws a random model of the same architecture);
+the MNIST images are not on disk, so the batch is synthetic (seeded; sparse stroke-like 28x28 images in [0, 1]).  The
+homomorphic result is checked against the same arithmetic in float64 (infer.jl:55-88 `do_encrypted_inference`):
 
     conv 7x7 stride 3, 4 channels (49 ciphertexts x plaintext scalars)  ->  + bias  ->  rescale        infer.jl:127-131
     square + relinearise + rescale                                                                      :136-138
@@ -69,14 +70,28 @@ def encrypted_matmul(gk, W, x, B):
     return result
 
 
-def run(logn=13, seed=0, verbose=True):
+GOLDEN_MODEL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "mnist_conv.npz")
+
+
+def load_model(path=GOLDEN_MODEL):
+    """the reference's trained weights; infer.jl:118-119 flips the Flux convolution kernel in both spatial dimensions"""
+    d = np.load(path)
+    m = {k: d[k].astype(np.float64) for k in d.files}
+    m["conv_w"] = m["conv_w"][::-1, ::-1, :].copy()
+    return m
+
+
+def run(logn=13, seed=0, verbose=True, model="reference"):
     N = 1 << logn
     B = N // 128                                                   # images per ciphertext
     rs = np.random.default_rng(seed)
-    model = {"conv_w": rs.normal(0, 0.15, (7, 7, 4)), "conv_b": rs.normal(0, 0.1, 4),
-             "fq1_w": rs.normal(0, 0.06, (64, 256)), "fq1_b": rs.normal(0, 0.1, 64),
-             "fq2_w": rs.normal(0, 0.1, (10, 64)), "fq2_b": rs.normal(0, 0.1, 10)}
-    batch = rs.random((B, 28, 28))
+    if model == "reference":
+        model = load_model()
+    else:
+        model = {"conv_w": rs.normal(0, 0.15, (7, 7, 4)), "conv_b": rs.normal(0, 0.1, 4),
+                 "fq1_w": rs.normal(0, 0.06, (64, 256)), "fq1_b": rs.normal(0, 0.1, 64),
+                 "fq2_w": rs.normal(0, 0.1, (10, 64)), "fq2_b": rs.normal(0, 0.1, 10)}
+    batch = (rs.random((B, 28, 28)) < 0.15) * rs.random((B, 28, 28))   # sparse strokes: MNIST-like pixel statistics
     want = plain_model(model, batch)
 
     # infer.jl:97-112: q0 (60 bit), five 40-bit primes, 60-bit special prime; ModulusRaised CKKS, sigma 3.2
@@ -131,5 +146,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--logn", type=int, default=13)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--model", default="reference", choices=["reference", "synthetic"])
     a = ap.parse_args()
-    run(a.logn, a.seed)
+    run(a.logn, a.seed, model=a.model)

@@ -78,6 +78,11 @@ int tfhe_memcpy_h2d(void *dst, const void *src, size_t bytes);  /* synchronous *
 int tfhe_memcpy_d2h(void *dst, const void *src, size_t bytes);  /* synchronous */
 int tfhe_memcpy_d2d(tfhe_ctx *ctx, void *dst, const void *src, size_t bytes); /* on the ctx stream */
 int tfhe_memset(tfhe_ctx *ctx, void *dst, int byte, size_t bytes);
+/* ciphertext staging: the reference keeps a ciphertext as a tuple of ring elements (CipherText.cs, rlwe_she.jl:131-136),
+ * the fused entry points take [batch][polys][limbs][N].  Component p of a packed batch [count][polys][words]
+ * <- / -> a batch of single polynomials [count][words] (words = limbs * N), one strided copy on the ctx stream. */
+int tfhe_pack_poly(tfhe_ctx *ctx, uint64_t *packed, const uint64_t *src, int polys, int p, size_t words, int64_t count);
+int tfhe_unpack_poly(tfhe_ctx *ctx, uint64_t *dst, const uint64_t *packed, int polys, int p, size_t words, int64_t count);
 
 /* ---- K1/K2: nntt / inntt --------------------------------------------------------------------
  * NTT.nntt / NTT.inntt on RingCoeffs (pow2_cyc_rings.jl:295-318), per limb as crt.jl:247-267.
@@ -146,7 +151,7 @@ int tfhe_ckks_decode(tfhe_ctx *ctx, int level, uint64_t scale_mant, int scale_ex
 
 /* ---- device-side samplers for RingSampler (poly.jl:7-23; RNS crt.jl:277-279) -- SURVEY §8(f) -------------------
  * The ring is limbs 0..level-1 of ctx; out: [count][level][N], coefficient domain.  The random stream is Philox4x32-10
- * keyed by `seed`, counter = (coefficient index of polynomial first_poly + p, attempt/limb, stream) -- defined in
+ * keyed by `seed`, counter = (coefficient index, polynomial index first_poly + p < 2^32, attempt/limb, stream) -- defined in
  * csrc/sample_kernels.h and restated in oracle/spec.py (Julia's generator cannot be matched).
  *   uniform : independent exactly-uniform residues per limb (rejection sampling).
  *   gaussian: multiplier * round(N(0, sigma^2)) (Box-Muller, ties to even), the same integer in every limb

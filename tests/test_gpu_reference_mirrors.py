@@ -1,0 +1,164 @@
+"""Mirrors of the reference tests that round 1 left out (VERDICT r01 "Missing 5"), driven through the host mirror with
+every ring operation on the device:
+
+  test/ckks_rotate.jl:8-45    rotation with relin_window = 1 digit keys (K14 on a two-limb ring)
+  test/ckks_matmul.jl:8-44    encrypted_matmul (diagonal method) with relin_window = 1 keys, steps = 4
+  test/bfv_simd.jl:10-31 + docs/src/man/encoding.md:69-91   SlotEncoding = the user-visible NTT order
+  test/bfv_noise.jl:5-34      invariant_noise_budget decreases along mul / keyswitch chains
+  test/ckks_triv.jl:7-33      encode -> square -> decode, encrypt -> c*c -> decrypt at scale 2^40
+
+Parameter sets the reference derives with BFVParams(p; eval_mult_count) (single big-integer moduli from the PALISADE-style
+estimator, out of scope per SURVEY §1) are replaced by RNS rings of at least that size; everything else is as in the tests."""
+import numpy as np
+import pytest
+
+import toyfhe_jl_amd as tf
+
+pytestmark = pytest.mark.gpu
+
+
+def chain(start, n, N):
+    out, p = [], tf.nextprime(start, 1, 2 * N)
+    for _ in range(n):
+        out.append(p)
+        p = tf.nextprime(p + 2 * N, 1, 2 * N)
+    return out
+
+
+def test_ckks_rotate_with_digit_window_keys():
+    """test/ckks_rotate.jl:8-45: N = 2^4, (q0, ps) two 40-bit primes, scale 2^60, CKKSParams(R, 1, 3.2) -- NO special prime:
+    the Galois keys are base-2 digit keys over the two-limb ring (81 key components)."""
+    N = 16
+    R = tf.NegacyclicRing(N, chain(2**40 + 1, 2, N))
+    scale = 2**60
+    plain = np.arange(1, N // 2 + 1).astype(complex)
+    plain[0] += 1j                                                             # ckks_rotate.jl:21
+    re = tf.ckks_encode(plain, R, scale)
+    assert np.abs(tf.ckks_decode(re.apply_galois_element(3), scale) - np.roll(plain, -1)).max() < 1e-9   # :24
+    params = tf.CKKSParams(R, 1, 3.2)
+    rng = np.random.default_rng(8)
+    kp = tf.keygen(rng, params)
+    c = tf.encrypt(rng, kp, re, scale=scale)
+    # :32-38: apply the automorphism to the ciphertext, switch from sigma_3(s) back to s
+    c3 = tf.apply_galois_element(c, 3)
+    ek = tf.make_eval_key(rng, kp.priv.secret.apply_galois_element(3), kp.priv)
+    assert len(ek.key) == R.modulus().bit_length()                            # ndigits(Q, base = 2), rlwe_she.jl:282
+    rt = tf.ckks_decode(tf.decrypt(kp, tf.keyswitch(ek, c3)), scale)
+    assert np.allclose(rt, np.roll(plain, -1), atol=1e-6)                      # :39
+    gk = tf.keygen_galois(rng, kp.priv, steps=1)
+    got = tf.ckks_decode(tf.decrypt(kp, tf.rotate(gk, tf.encrypt(rng, kp, re, scale=scale))), scale)
+    assert np.allclose(got, np.roll(plain, 1), atol=1e-6)                      # :43-45
+
+
+def test_ckks_matmul_with_digit_window_keys():
+    """test/ckks_matmul.jl:8-44: N = 2^5, three 40-bit primes, scale 2^40, relin_window = 1, Galois key for 4 steps,
+    encrypted_matmul by diagonals with a 4 x 4 matrix of ones."""
+    N = 32
+    R = tf.NegacyclicRing(N, chain(2**40 + 1, 3, N))
+    scale = 2**40
+    plain = np.arange(1, N // 2 + 1).astype(complex)
+    W = np.ones((4, 4), dtype=np.float32)
+    params = tf.CKKSParams(R, 1, 3.2)
+    rng = np.random.default_rng(9)
+    kp = tf.keygen(rng, params)
+    c = tf.encrypt(rng, kp, tf.ckks_encode(plain, R, scale), scale=scale)
+    gk = tf.keygen_galois(rng, kp.priv, steps=4)
+
+    def encrypted_matmul(gk, weights, x):                                      # ckks_matmul.jl:33-41
+        n = weights.shape[1]
+        result = x.mul_plain(np.tile(np.diag(weights), n))                    # repeat(diag(weights), n) .* x
+        rotated = x
+        for k in range(2, n + 1):
+            rotated = tf.rotate(gk, rotated)
+            result = result + rotated.mul_plain(np.tile(np.diag(np.roll(weights, k - 1, axis=1)), n))
+        return result
+
+    res = encrypted_matmul(gk, W, c)
+    got = tf.ckks_decode(tf.decrypt(kp, res), res.scale)
+    want = (W.astype(float) @ plain.reshape((4, 4), order="F").T).T            # (W * reshape(plain,4,4)')'
+    assert np.allclose(got.reshape((4, 4), order="F"), want, atol=1e-5)        # :43
+
+
+def test_slot_encoding_is_the_device_ntt_order():
+    """docs/src/man/encoding.md:69-91 (and src/encoding.jl:35-52): the plaintext slots are the NTT-domain coefficients in the
+    library's natural order -- a[0:9] = 1:10, b[:] .= 10, SlotEncoding(a * b)[0:10] = 10, 20, ..., 100, 0 -- through the
+    device transforms of the plaintext ring Z_65537[x]/(x^2048 + 1)."""
+    Rt = tf.NegacyclicRing(2048, [65537])
+    a = tf.she.slot_encode(Rt, list(range(1, 11)) + [0] * 2038)
+    b = tf.she.slot_encode(Rt, [10] * 2048)
+    assert a.primal is None and b.primal is None
+    a = tf.RingElement(Rt, a.coeffs_primal(), None)                            # force the product through inntt -> nntt
+    b = tf.RingElement(Rt, b.coeffs_primal(), None)
+    prod = a * b
+    slots = tf.she.slot_decode(prod)
+    assert slots[:11] == [10, 20, 30, 40, 50, 60, 70, 80, 90, 100, 0] and not any(slots[11:])
+    # a constant slot vector is the constant polynomial
+    assert b.to_ints() == [10] + [0] * 2047
+
+
+def test_bfv_simd():
+    """test/bfv_simd.jl:10-31: t = 65537, slot-wise product under encryption."""
+    n, t = 2048, 65537
+    ch = chain(2**50 + 1, 5, n)
+    Rbig = tf.NegacyclicRing(n, ch)
+    R = Rbig.crtselect(range(2))
+    Rt = tf.NegacyclicRing(n, [t])
+    params = tf.BFVParams(R, Rbig, t, 0, 3.2)
+    rng = np.random.default_rng(10)
+    kp = tf.keygen(rng, params)
+    plain = tf.she.slot_encode(Rt, [1, 1] + [0] * (n - 2))                     # plain[0] = plain[1] = 1
+    plain2 = tf.she.slot_encode(Rt, [5] + [10] * (n - 1))                      # plain2[:] .= 10; plain2[0] = 5
+    c1 = tf.encrypt(rng, kp, plain.to_ints())
+    c2 = tf.encrypt(rng, kp, plain2.to_ints())
+    y = c1 * c2
+    data = tf.she.slot_decode(Rt(tf.decrypt(kp, y)))
+    assert data[0] == 5 and data[1] == 10 and not any(data[2:])               # :27-31
+
+
+def test_bfv_noise_budget_decreases():
+    """test/bfv_noise.jl:5-34: invariant_noise_budget (bfv.jl:137-166) shrinks with every multiplication, and a key switch
+    costs little; t = 7, three multiplications."""
+    n, t = 2048, 7
+    ch = chain(2**50 + 1, 7, n)
+    Rbig = tf.NegacyclicRing(n, ch)
+    R = Rbig.crtselect(range(3))
+    params = tf.BFVParams(R, Rbig, t, 0, 3.2)
+    rng = np.random.default_rng(11)
+    kp1 = tf.keygen(rng, params)
+    ek = tf.keygen_evalmult(rng, kp1.priv)
+    c1 = tf.encrypt(rng, kp1, [2] + [0] * (n - 1))
+    b1 = tf.invariant_noise_budget(kp1.priv, c1)
+    c1squared = c1 * c1
+    b2 = tf.invariant_noise_budget(kp1.priv, c1squared)
+    assert b2 < b1                                                             # :19
+    cswitch1 = tf.keyswitch(ek, c1squared)
+    bswitch1 = tf.invariant_noise_budget(kp1.priv, cswitch1)
+    cswitchmul = cswitch1 * c1
+    bswitchmul = tf.invariant_noise_budget(kp1.priv, cswitchmul)
+    assert bswitchmul < bswitch1 < b1                                          # :24
+    cswitch2 = tf.keyswitch(ek, cswitchmul)
+    bswitch2 = tf.invariant_noise_budget(kp1.priv, cswitch2)
+    cswitchmul2 = cswitch2 * c1
+    bswitchmul2 = tf.invariant_noise_budget(kp1.priv, cswitchmul2)
+    assert bswitchmul2 < bswitch2 < bswitch1                                   # :29
+    assert bswitchmul2 > 1                                                     # still decrypts: 2^4 = 16 = 2 (mod 7)
+    assert tf.decrypt(kp1, cswitchmul2)[0] == 16 % t
+
+
+def test_ckks_triv():
+    """test/ckks_triv.jl:7-33: N/2 = 2048 slots, LinRange(0, 1, 2048) at scale 2^40; encode -> re*re -> decode at scale^2;
+    encrypt -> decrypt; c*c (3-element) -> decrypt; all atol 1e-4."""
+    N = 4096
+    R = tf.NegacyclicRing(N, chain(2**50 + 1, 3, N))                           # >= 2^80 * headroom, as the estimator's ring
+    scale = 2**40
+    x = np.linspace(0.0, 1.0, N // 2)
+    re = tf.ckks_encode(x.astype(complex), R, scale)
+    assert np.allclose(tf.ckks_decode(re * re, scale * scale).real, x**2, atol=1e-4)     # :24
+    params = tf.CKKSParams(R, 0, 3.2)
+    rng = np.random.default_rng(12)
+    kp = tf.keygen(rng, params)
+    c = tf.encrypt(rng, kp, re, scale=scale)
+    assert np.allclose(tf.ckks_decode(tf.decrypt(kp, c), scale).real, x, atol=1e-4)       # :31
+    cc = c * c
+    assert len(cc) == 3
+    assert np.allclose(tf.ckks_decode(tf.decrypt(kp, cc), cc.scale).real, x**2, atol=1e-4)  # :32

@@ -159,7 +159,8 @@ def test_ckks_modswitch():
 def test_ckks_modraise_keyswitch_and_rotate():
     """test/ckks_modraise.jl:10-30 (keyswitch s->s with the special prime, atol 1e-8) and the rotation of
     test/ckks_rotate.jl:43-45 on the same ModulusRaised parameters (upstream's rotate test uses
-    relin_window=1 digit keys, which are host-only; the special-prime path is what infer.jl uses)."""
+    relin_window=1 digit keys -- mirrored with K14 in test_ckks_rotate_and_matmul_with_digit_window_keys; the special-prime
+    path here is what infer.jl uses)."""
     N = 32
     R = _ckks_ring(N, 3)
     params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
@@ -213,12 +214,12 @@ def test_device_samplers_match_the_stream_definition():
     got = out.to_numpy((count, 3, N))
     for p in range(count):
         for l, q in enumerate(qs):
-            want = [spec.sample_uniform_mod((first + p) * N + k, l, 0, seed, q) for k in range(N)]
+            want = [spec.sample_uniform_mod(((first + p) << 32) | k, l, 0, seed, q) for k in range(N)]
             assert [int(x) for x in got[p, l]] == want
     assert all(int(got[:, l].max()) < q for l, q in enumerate(qs))
     ctx.sample_gaussian(3, 3.2, 1, seed, 1, first, out.ptr, count)
     g = out.to_numpy((count, 3, N))
-    want = np.array([[spec.sample_gauss_int((first + p) * N + k, 1, seed, 3.2) for k in range(N)] for p in range(count)])
+    want = np.array([[spec.sample_gauss_int(((first + p) << 32) | k, 1, seed, 3.2) for k in range(N)] for p in range(count)])
     cent = np.where(g[:, 0] > qs[0] // 2, g[:, 0].astype(np.int64) - qs[0], g[:, 0].astype(np.int64))
     assert (cent != want).mean() < 0.01
     for l, q in enumerate(qs):                                       # the same integer in every limb
@@ -263,5 +264,5 @@ def test_encrypted_cnn_inference_pipeline():
     spec_ = importlib.util.spec_from_file_location("encrypted_mnist", os.path.join(os.path.dirname(__file__), "..", "examples", "encrypted_mnist.py"))
     mod = importlib.util.module_from_spec(spec_)
     spec_.loader.exec_module(mod)
-    err, rng_ = mod.run(logn=11, seed=3, verbose=False)
+    err, rng_ = mod.run(logn=11, seed=3, verbose=False, model="synthetic")
     assert err < 1e-4 * max(1.0, rng_), err

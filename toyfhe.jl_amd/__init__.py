@@ -10,5 +10,5 @@ from . import ring, she  # noqa: F401,E402
 from .ring import NegacyclicRing, RingElement, nextprime  # noqa: F401,E402
 from . import wire  # noqa: F401,E402
 from .she import (DeviceRng, BFVParams, BGVParams, CKKSParams, CipherText, ModulusRaised, apply_galois_element,  # noqa: F401,E402
-                  ckks_decode, ckks_encode, decrypt, enc_mul, encrypt, keygen, keygen_evalmult, keygen_galois,
+                  ckks_decode, ckks_encode, decrypt, enc_mul, encrypt, invariant_noise_budget, keygen, keygen_evalmult, keygen_galois,
                   keyswitch, make_eval_key, modswitch, rotate)

@@ -1,7 +1,9 @@
 // sample_kernels.h -- device-side samplers for RingSampler (src/poly.jl:7-23, RNS variant src/crt.jl:277-279): uniform
 // residues and rounded-Gaussian noise, so that keygen / encrypt can run without a host round trip.
 // Randomness cannot match Julia's generator; the stream is defined here instead: Philox4x32-10
-// (Salmon, Moraes, Dror, Shaw, SC'11), key = seed, counter = (coefficient index, attempt | limb, stream id).
+// (Salmon, Moraes, Dror, Shaw, SC'11), key = seed, counter = (coefficient index, polynomial index, attempt | limb, stream id):
+// the polynomial counter and the coefficient index live in separate counter words, so draws for rings of different degree
+// never share a counter.  A statistical generator for reproducible experiments, NOT a cryptographically secure one.
 // oracle/spec.py carries the same definition; the uniform sampler is checked bit-for-bit against it.
 #pragma once
 #include <math.h>
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void k_sample_uniform(u64* __restrict__ out, c
     const u32 k = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
     const u64 p = blockIdx.z;
     if (k >= n) return;
-    out[((size_t)p * level + l) * n + k] = sample_uniform_mod((first_poly + p) * n + k, l, stream, seed, LT[l].q);
+    out[((size_t)p * level + l) * n + k] = sample_uniform_mod(((first_poly + p) << 32) | k, l, stream, seed, LT[l].q);
 }
 // out [count][level][N]: mult * e with e ~ round(N(0, sigma^2)), the same integer reduced into every limb
 __global__ __launch_bounds__(256) void k_sample_gaussian(u64* __restrict__ out, const ntt_limb_t* __restrict__ LT, int level, double sigma,
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void k_sample_gaussian(u64* __restrict__ out, 
     const u32 k = blockIdx.x * 256 + threadIdx.x;
     const u64 p = blockIdx.y;
     if (k >= n) return;
-    const long long e = sample_gauss_int((first_poly + p) * n + k, stream, seed, sigma);
+    const long long e = sample_gauss_int(((first_poly + p) << 32) | k, stream, seed, sigma);
     const u64 mag = (u64)(e < 0 ? -e : e);
     for (int l = 0; l < level; l++) {
         const barrett_t& bt = LT[l].br;

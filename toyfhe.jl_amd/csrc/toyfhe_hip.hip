@@ -590,6 +590,23 @@ int tfhe_memcpy_d2d(tfhe_ctx* c, void* d, const void* s, size_t n) {
     HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream));
     return TFHE_OK;
 }
+// component p of a packed batch [count][polys][words] <-> a batch of single polynomials [count][words]: one strided copy
+int tfhe_pack_poly(tfhe_ctx* c, uint64_t* packed, const uint64_t* src, int polys, int p, size_t words, int64_t count) {
+    if (!c || !packed || !src) return fail(TFHE_E_BADARG, "null argument");
+    if (polys < 1 || p < 0 || p >= polys || count < 0) return fail(TFHE_E_BADARG, "bad component index");
+    if (count == 0 || words == 0) return TFHE_OK;
+    HIP_TRY(hipMemcpy2DAsync(packed + (size_t)p * words, (size_t)polys * words * 8, src, words * 8, words * 8, (size_t)count,
+                             hipMemcpyDeviceToDevice, c->stream));
+    return TFHE_OK;
+}
+int tfhe_unpack_poly(tfhe_ctx* c, uint64_t* dst, const uint64_t* packed, int polys, int p, size_t words, int64_t count) {
+    if (!c || !packed || !dst) return fail(TFHE_E_BADARG, "null argument");
+    if (polys < 1 || p < 0 || p >= polys || count < 0) return fail(TFHE_E_BADARG, "bad component index");
+    if (count == 0 || words == 0) return TFHE_OK;
+    HIP_TRY(hipMemcpy2DAsync(dst, words * 8, packed + (size_t)p * words, (size_t)polys * words * 8, words * 8, (size_t)count,
+                             hipMemcpyDeviceToDevice, c->stream));
+    return TFHE_OK;
+}
 int tfhe_memset(tfhe_ctx* c, void* d, int byte, size_t n) {
     if (!c) return fail(TFHE_E_BADARG, "null context");
     HIP_TRY(hipMemsetAsync(d, byte, n, c->stream));
@@ -1136,6 +1153,7 @@ int tfhe_sample_uniform(tfhe_ctx* c, int level, uint64_t seed, uint32_t stream, 
     if (!c || !out) return fail(TFHE_E_BADARG, "null argument");
     if (level < 1 || level > c->L) return fail(TFHE_E_LEVEL_MISMATCH, "level=%d outside [1,%d]", level, c->L);
     if (count < 0) return fail(TFHE_E_BADARG, "negative count");
+    if (first_poly + (u64)count > (1ull << 32)) return fail(TFHE_E_BADARG, "polynomial counter exceeds 2^32");
     const u32 n = (u32)c->N;
     for (int64_t p0 = 0; p0 < count; p0 += 32768) {
         const unsigned np = (unsigned)std::min<int64_t>(32768, count - p0);
@@ -1151,6 +1169,7 @@ int tfhe_sample_gaussian(tfhe_ctx* c, int level, double sigma, uint64_t multipli
     if (level < 1 || level > c->L) return fail(TFHE_E_LEVEL_MISMATCH, "level=%d outside [1,%d]", level, c->L);
     if (!(sigma >= 0) || sigma > 1e15) return fail(TFHE_E_BADARG, "sigma out of range");
     if (count < 0) return fail(TFHE_E_BADARG, "negative count");
+    if (first_poly + (u64)count > (1ull << 32)) return fail(TFHE_E_BADARG, "polynomial counter exceeds 2^32");
     const u32 n = (u32)c->N;
     for (int64_t p0 = 0; p0 < count; p0 += 32768) {
         const unsigned np = (unsigned)std::min<int64_t>(32768, count - p0);

@@ -124,6 +124,9 @@ class NegacyclicRing:
         already in RNS form as a uint64 array [..., L, N]."""
         return RingElement.from_host(self, coeffs)
 
+    def from_residues(self, residues, dual=False) -> "RingElement":
+        return RingElement.from_residues(self, residues, dual=dual)
+
     def zero(self, batch=None) -> "RingElement":
         n = (batch or 1) * self.L * self.N
         buf = DeviceBuffer(n)
@@ -157,8 +160,13 @@ class RingElement:
         a = coeffs
         L, N = ring.L, ring.N
         if isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.shape[-2:] == (L, N):
+            # a uint64 array is ALWAYS taken as RNS residues [..., L, N] (see from_residues); integer coefficients go in as
+            # Python ints or signed arrays.  The kernels assume reduced inputs, so check them here.
             res = a
             batch = None if a.ndim == 2 else int(np.prod(a.shape[:-2]))
+            for l, q in enumerate(ring.moduli):
+                if res.size and int(res[..., l, :].max()) >= q:
+                    raise AssertionError(f"residue out of range on limb {l} (must be < {q})")
         else:
             rows = [list(a)] if not hasattr(a[0], "__len__") else [list(r) for r in a]
             batch = None if not hasattr(a[0], "__len__") else len(rows)
@@ -169,6 +177,14 @@ class RingElement:
                     res[b, l] = [int(x) % q for x in r]
         buf = DeviceBuffer.from_numpy(res)
         return cls(ring, dual=buf, batch=batch) if dual else cls(ring, primal=buf, batch=batch)
+
+    @classmethod
+    def from_residues(cls, ring, residues, dual=False) -> "RingElement":
+        """explicit residue path: `residues` uint64 [L][N] (one element) or [B][L][N] (a batch), each limb reduced"""
+        a = np.ascontiguousarray(residues, dtype=np.uint64)
+        if a.shape[-2:] != (ring.L, ring.N) or a.ndim not in (2, 3):
+            raise AssertionError(f"residues must have shape [{ring.L}][{ring.N}] or [B][{ring.L}][{ring.N}]")
+        return cls.from_host(ring, a, dual=dual)
 
     def to_numpy(self, domain="primal") -> np.ndarray:
         buf = self.coeffs_primal() if domain == "primal" else self.coeffs_dual()

@@ -29,8 +29,14 @@ from .ring import NegacyclicRing, RingElement
 
 class DeviceRng:
     """Counter-based generator for the device samplers (tfhe_sample_uniform / tfhe_sample_gaussian): Philox4x32-10 keyed by
-    `seed`; every draw of a polynomial advances the polynomial counter, every sampler call site its own stream id.
-    Passing a DeviceRng where the mirror takes an `rng` makes keygen / encrypt sample on the GPU (no host round trip)."""
+    the 64-bit `seed`.  Every draw of a polynomial takes a fresh value of the polynomial counter, which is its own counter
+    word (separate from the coefficient index), so no two draws -- for rings of any degree -- ever share a counter; uniform
+    and Gaussian draws additionally use different stream ids (0 / 1).  Passing a DeviceRng where the mirror takes an `rng`
+    makes keygen / encrypt sample on the GPU (no host round trip).
+
+    This is a reproducible statistical generator for tests and benchmarks, NOT a cryptographically secure one (64-bit key,
+    Philox is not a CSPRNG): production keys must come from a CSPRNG on the host (`numpy.random.Generator` over
+    `os.urandom`-seeded state is accepted wherever an `rng` is)."""
 
     def __init__(self, seed: int):
         self.seed, self.next_poly = int(seed) & (2**64 - 1), 0
@@ -268,7 +274,7 @@ class KeySwitchKey:
             for i, kc in enumerate(self.key):
                 for s, el in enumerate((kc.mask, kc.masked)):
                     native.check(native.lib().tfhe_memcpy_d2d(ring.ctx.h, buf.ptr + ((i * 2 + s) * sz) * 8,
-                                                              el.coeffs_dual().ptr, sz * 8))
+                                                              el.coeffs_dual().ptr, sz * 8))   # once per key
             ring.ctx.sync()
             self._packed = buf
         return self._packed
@@ -328,6 +334,8 @@ class CipherText:
 
     def __mul__(self, o):
         if isinstance(o, CipherText):
+            if (self.scale is None) != (o.scale is None):
+                raise UsageError("multiplying a scaled (CKKS) ciphertext by an unscaled one")
             scale = None if self.scale is None else self.scale * o.scale  # ckksencoding.jl:133-135
             return CipherText(self.params, enc_mul(self, o), scale)
         if isinstance(o, int):
@@ -426,6 +434,40 @@ def decrypt(key, c: CipherText):
     return priv.params.decode(b)
 
 
+def invariant_noise_budget(key, c: CipherText) -> float:
+    """invariant_noise_budget(pk::PrivKey{BFVParams}, c), bfv.jl:137-166:
+    log2(q) - log2(t) - 1 - max_i log2(birem(b_i)) with b = c_1 + s c_2 + s^2 c_3 ... and birem(x) = min(x mod Δ, Δ - x mod Δ).
+    A host-side diagnostic over the device ring ops (one ciphertext, not a batch)."""
+    priv = key.priv if isinstance(key, KeyPair) else key
+    params = priv.params
+    if not isinstance(params, BFVParams) or c[0].batch is not None:
+        raise NotImplementedError("invariant_noise_budget: single BFV ciphertexts")
+    b, spow = c[0], priv.secret
+    for i in range(1, len(c)):
+        b = b + spow * c[i]
+        if i + 1 < len(c):
+            spow = spow * priv.secret
+    delta = params.delta
+
+    def birem(x):
+        r = x % delta
+        return delta - r if r > delta // 2 else r
+    worst = max(birem(x) for x in b.to_ints())
+    return math.log2(params.ring.modulus()) - math.log2(params.t) - 1 - (math.log2(worst) if worst else 0.0)
+
+
+def slot_encode(plain_ring: NegacyclicRing, slots) -> RingElement:
+    """SlotEncoding -> RingElement (encoding.jl:35-52): the slots ARE the NTT-domain (dual) coefficients, natural order."""
+    vals = [int(v) % plain_ring.moduli[0] for v in slots]
+    res = np.array([vals], dtype=np.uint64)
+    return RingElement.from_host(plain_ring, res, dual=True)
+
+
+def slot_decode(el: RingElement):
+    """SlotEncoding(r) (encoding.jl:35-43): coeffs_dual of a plaintext ring element."""
+    return [int(v) for v in el.to_numpy("dual")[0]]
+
+
 # --------------------------------------------------------------------------------------------------
 # multiplication (rlwe_she.jl:247-266 + bfv.jl:34-40)
 # --------------------------------------------------------------------------------------------------
@@ -458,27 +500,29 @@ def enc_mul(c1: CipherText, c2: CipherText):
     return tuple(cs)
 
 
-def _pack(bufs, ring, n) -> DeviceBuffer:
-    """[poly](n, L, N) -> (n, polys, L, N)"""
+def _pack(bufs, ring, n, ctx=None) -> DeviceBuffer:
+    """[poly](n, L, N) -> (n, polys, L, N): one strided device copy per component, on the stream of `ctx` (the context that
+    will consume the packed batch)."""
+    ctx = ctx or ring.ctx
     P, sz = len(bufs), ring.L * ring.N
     out = DeviceBuffer(n * P * sz)
     lib = native.lib()
     for p, b in enumerate(bufs):
-        for k in range(n):
-            native.check(lib.tfhe_memcpy_d2d(ring.ctx.h, out.ptr + ((k * P + p) * sz) * 8, b.ptr + (k * sz) * 8, sz * 8))
+        native.check(lib.tfhe_pack_poly(ctx.h, out.ptr, b.ptr, P, p, sz, n))
     return out
 
 
-def _unpack(buf, ring, n, P, batch, primal=True):
+def _unpack(buf, ring, n, P, batch, primal=True, ctx=None):
+    """(n, P, L, N) -> P ring elements of shape (n, L, N), on the stream of `ctx` (the context that produced `buf`)."""
+    ctx = ctx or ring.ctx
     sz = ring.L * ring.N
     lib = native.lib()
     outs = []
     for p in range(P):
         o = DeviceBuffer(n * sz)
-        for k in range(n):
-            native.check(lib.tfhe_memcpy_d2d(ring.ctx.h, o.ptr + (k * sz) * 8, buf.ptr + ((k * P + p) * sz) * 8, sz * 8))
+        native.check(lib.tfhe_unpack_poly(ctx.h, o.ptr, buf.ptr, P, p, sz, n))
         outs.append(RingElement(ring, o, None, batch) if primal else RingElement(ring, None, o, batch))
-    ring.ctx.sync()  # `buf` may be released by the caller as soon as we return
+    ctx.sync()  # `buf` may be released by the caller as soon as we return
     return tuple(outs)
 
 
@@ -554,14 +598,18 @@ def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
     level = ring.L
     if keyring.idx != list(range(keyring.L)) or ring.idx != list(range(level)):
         raise UsageError("ciphertext ring is not a prefix of the key ring")
+    if ring.ctx is not keyring.ctx and (ring.N != keyring.N or ring.moduli != keyring.moduli[:level] or ring.psi != keyring.psi[:level]):
+        raise UsageError("ciphertext and key belong to different rings")
     sz = level * ring.N
-    ct = _pack([x.coeffs_primal() for x in c.cs], ring, n)
+    if ring.ctx is not keyring.ctx:
+        ring.ctx.sync()                                    # the components were produced on the ciphertext ring's stream
+    ct = _pack([x.coeffs_primal() for x in c.cs], ring, n, ctx=keyring.ctx)
     out = DeviceBuffer(n * 2 * sz)
     if _galois is None:
         keyring.ctx.keyswitch(keyring.L, level, special, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n)
     else:
         keyring.ctx.rotate(keyring.L, level, special, ek.packed().ptr, len(ek.key), _galois, ct.ptr, out.ptr, n)
-    return CipherText(c.params, _unpack(out, ring, n, 2, batch, primal=True), c.scale)
+    return CipherText(c.params, _unpack(out, ring, n, 2, batch, primal=True, ctx=keyring.ctx), c.scale)
 
 
 def apply_galois_element(c: CipherText, g: int) -> CipherText:
@@ -649,7 +697,7 @@ def dump_ciphertext(c: CipherText) -> bytes:
     ring = c[0].ring
     res = np.stack([x.to_numpy("primal").reshape(x.count, ring.L, ring.N) for x in c.cs], axis=1)
     scale = scale_parts(c.scale) if c.scale is not None else (0, 0)
-    return wire.dump(res, ring.moduli, ring.psi, kind=wire.KIND_CIPHERTEXT, domain=0, scale=scale)
+    return wire.dump(res, ring.moduli, ring.psi, kind=wire.KIND_CIPHERTEXT, domain=0, scale=scale, unbatched=c[0].batch is None)
 
 
 def load_ciphertext(blob: bytes, params) -> CipherText:
@@ -666,7 +714,7 @@ def load_ciphertext(blob: bytes, params) -> CipherText:
         raise UsageError("blob ring does not match the parameters' ciphertext ring")
     res = d["residues"]
     batch = res.shape[0]
-    cs = [RingElement.from_host(ring, res[:, p]) for p in range(d["polys"])]
+    cs = [RingElement.from_host(ring, res[0, p] if d["unbatched"] else res[:, p]) for p in range(d["polys"])]
     smant, sexp = d["scale"]
     scale = None if smant == 0 else Fraction(smant) * Fraction(2) ** sexp
     return CipherText(params, cs, scale)

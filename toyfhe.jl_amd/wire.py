@@ -7,7 +7,7 @@ The reference has no serialisation; its in-memory layout is the `StructArray` So
     offset  size  field
     0       8     magic  b"TFHEWIRE"
     8       4     version (= 1)                      little-endian throughout
-    12      4     kind: 1 ring elements / ciphertext, 2 key-switch key
+    12      4     kind (low 8 bits): 1 ring elements / ciphertext, 2 key-switch key; bit 8: a single unbatched element (count = 1)
     16      4     log2(N)
     20      4     L (limbs)
     24      4     polys (ciphertext components; key: 2 = (mask, masked))
@@ -28,6 +28,7 @@ import numpy as np
 MAGIC = b"TFHEWIRE"
 VERSION = 1
 KIND_CIPHERTEXT, KIND_KEY = 1, 2
+FLAG_UNBATCHED = 0x100
 _HDR = struct.Struct("<8sIIIIIIQQiI")
 
 
@@ -35,7 +36,7 @@ class WireError(ValueError):
     pass
 
 
-def dump(residues, moduli, psis, *, kind=KIND_CIPHERTEXT, domain=0, scale=(0, 0), relin_window=0) -> bytes:
+def dump(residues, moduli, psis, *, kind=KIND_CIPHERTEXT, domain=0, scale=(0, 0), relin_window=0, unbatched=False) -> bytes:
     """residues: uint64 array [count][polys][L][N] (or [polys][L][N] for count = 1)."""
     a = np.ascontiguousarray(residues, dtype="<u8")
     if a.ndim == 3:
@@ -49,12 +50,14 @@ def dump(residues, moduli, psis, *, kind=KIND_CIPHERTEXT, domain=0, scale=(0, 0)
     for l, q in enumerate(moduli):
         if a[:, :, l, :].max(initial=0) >= q:
             raise WireError(f"residue out of range in limb {l}")
-    hdr = _HDR.pack(MAGIC, VERSION, kind, logn, L, polys, domain, count, int(scale[0]), int(scale[1]), relin_window)
+    if unbatched and count != 1:
+        raise WireError("an unbatched element has count 1")
+    hdr = _HDR.pack(MAGIC, VERSION, kind | (FLAG_UNBATCHED if unbatched else 0), logn, L, polys, domain, count, int(scale[0]), int(scale[1]), relin_window)
     return hdr + np.asarray(moduli, dtype="<u8").tobytes() + np.asarray(psis, dtype="<u8").tobytes() + a.tobytes()
 
 
 def load(blob: bytes):
-    """-> dict(kind, N, moduli, psis, polys, domain, count, scale, relin_window, residues[count][polys][L][N])"""
+    """-> dict(kind, N, moduli, psis, polys, domain, count, scale, relin_window, unbatched, residues[count][polys][L][N])"""
     if len(blob) < _HDR.size:
         raise WireError("truncated header")
     magic, ver, kind, logn, L, polys, domain, count, smant, sexp, window = _HDR.unpack_from(blob, 0)
@@ -62,6 +65,9 @@ def load(blob: bytes):
         raise WireError("bad magic")
     if ver != VERSION:
         raise WireError(f"unsupported version {ver}")
+    unbatched, kind = bool(kind & FLAG_UNBATCHED), kind & ~FLAG_UNBATCHED
+    if unbatched and count != 1:
+        raise WireError("bad header field")
     if kind not in (KIND_CIPHERTEXT, KIND_KEY) or domain not in (0, 1) or not (1 <= logn <= 17) or L < 1 or polys < 1:
         raise WireError("bad header field")
     N = 1 << logn
@@ -76,4 +82,4 @@ def load(blob: bytes):
         if res[:, :, l, :].max(initial=0) >= q:
             raise WireError(f"residue out of range in limb {l}")
     return {"kind": kind, "N": N, "moduli": moduli, "psis": psis, "polys": polys, "domain": domain, "count": count,
-            "scale": (smant, sexp), "relin_window": window, "residues": res.astype(np.uint64)}
+            "scale": (smant, sexp), "relin_window": window, "unbatched": unbatched, "residues": res.astype(np.uint64)}
