@@ -81,9 +81,12 @@ def load_model(path=GOLDEN_MODEL):
     return m
 
 
-def run(logn=13, seed=0, verbose=True, model="reference"):
+def run(logn=13, seed=0, verbose=True, model="reference", batches=1):
+    """`batches` = K ciphertext sets evaluated together (K * B images): every ring element carries a leading batch dimension
+    of K, so each device call covers K ciphertexts (the batch the engine shards across GPUs)."""
     N = 1 << logn
     B = N // 128                                                   # images per ciphertext
+    K = int(batches)
     rs = np.random.default_rng(seed)
     if model == "reference":
         model = load_model()
@@ -91,7 +94,7 @@ def run(logn=13, seed=0, verbose=True, model="reference"):
         model = {"conv_w": rs.normal(0, 0.15, (7, 7, 4)), "conv_b": rs.normal(0, 0.1, 4),
                  "fq1_w": rs.normal(0, 0.06, (64, 256)), "fq1_b": rs.normal(0, 0.1, 64),
                  "fq2_w": rs.normal(0, 0.1, (10, 64)), "fq2_b": rs.normal(0, 0.1, 10)}
-    batch = (rs.random((B, 28, 28)) < 0.15) * rs.random((B, 28, 28))   # sparse strokes: MNIST-like pixel statistics
+    batch = (rs.random((K * B, 28, 28)) < 0.15) * rs.random((K * B, 28, 28))   # sparse strokes: MNIST-like pixel statistics
     want = plain_model(model, batch)
 
     # infer.jl:97-112: q0 (60 bit), five 40-bit primes, 60-bit special prime; ModulusRaised CKKS, sigma 3.2
@@ -110,7 +113,9 @@ def run(logn=13, seed=0, verbose=True, model="reference"):
     scale = 2**40
     I = public_preprocess(batch)
     cring = params.R_cipher()
-    C = [[tf.encrypt(rng, kp, tf.ckks_encode(I[i, j].T.reshape(-1), cring, scale), scale=scale) for j in range(7)] for i in range(7)]
+    def slots(m):                                                  # [K*B images][64 windows] -> [K][N/2], slot = window * B + image
+        return m.reshape(K, B, 64).transpose(0, 2, 1).reshape(K, -1)
+    C = [[tf.encrypt(rng, kp, tf.ckks_encode(slots(I[i, j]), cring, scale), scale=scale) for j in range(7)] for i in range(7)]
     t_setup = time.perf_counter() - t0
 
     t0 = time.perf_counter()
@@ -131,15 +136,16 @@ def run(logn=13, seed=0, verbose=True, model="reference"):
     sq2 = tf.modswitch(tf.keyswitch(ek, fq1 * fq1))
     W2 = np.vstack([model["fq2_w"], np.zeros((54, 64))])
     res = encrypted_matmul(gk, W2, sq2, B).add_plain(np.repeat(np.concatenate([model["fq2_b"], np.zeros(54)]), B))
-    got = tf.ckks_decode(tf.decrypt(kp, res), res.scale).real.reshape(64, B)[:10]
+    dec = tf.ckks_decode(tf.decrypt(kp, res), res.scale).real       # [K][N/2]
+    got = dec.reshape(K, 64, B)[:, :10].transpose(1, 0, 2).reshape(10, K * B)
     t_eval = time.perf_counter() - t0
     err = float(np.abs(got - want).max())
     if verbose:
-        print(f"N=2^{logn}, {B} images per ciphertext: setup {t_setup:.1f} s, encrypted evaluation {t_eval:.1f} s "
-              f"(49 encrypted inputs, 5 x 63 rotations, 5 relinearisations)")
-        print(f"max |encrypted - plaintext| over the 10 x {B} logits: {err:.3e}   (logit range +-{np.abs(want).max():.2f})")
+        print(f"N=2^{logn}, {K} x {B} images: setup {t_setup:.2f} s, encrypted evaluation {t_eval:.2f} s = {K * B / t_eval:.0f} images/s "
+              f"(49 encrypted inputs, 5 x 63 rotations, 5 relinearisations per ciphertext set)")
+        print(f"max |encrypted - plaintext| over the 10 x {K * B} logits: {err:.3e}   (logit range +-{np.abs(want).max():.2f})")
         print("argmax agreement:", float((got.argmax(0) == want.argmax(0)).mean()))
-    return err, float(np.abs(want).max())
+    return err, float(np.abs(want).max()), float((got.argmax(0) == want.argmax(0)).mean())
 
 
 if __name__ == "__main__":
@@ -147,5 +153,6 @@ if __name__ == "__main__":
     ap.add_argument("--logn", type=int, default=13)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--model", default="reference", choices=["reference", "synthetic"])
+    ap.add_argument("--batches", type=int, default=1, help="ciphertext sets evaluated together (images = batches * N/128)")
     a = ap.parse_args()
-    run(a.logn, a.seed, model=a.model)
+    run(a.logn, a.seed, model=a.model, batches=a.batches)

@@ -71,9 +71,16 @@ int tfhe_ctx_sync(tfhe_ctx *ctx);
  * forward), no read-once digit lift -- 1, 2 and 3 are cross-check paths for tests */
 int tfhe_ctx_set_ntt_variant(tfhe_ctx *ctx, int variant);
 
-/* ---- device memory helpers (for callers without a GPU array package) ------------------------- */
+/* ---- device memory helpers (for callers without a GPU array package) -------------------------
+ * tfhe_malloc / tfhe_free are a size-bucketed recycling allocator (csrc/dev_alloc.h): the reference allocates a fresh array
+ * per ring operation (e.g. broadcast results, pow2_cyc_rings.jl:167,200-214), so the mirror frees and allocates thousands of
+ * equally sized buffers per circuit.  tfhe_free never synchronises: the block is parked behind events recorded on every
+ * live context's stream and is handed out again only once they have completed.  TFHE_ALLOC_CACHE=0 selects plain
+ * hipMalloc / hipFree.  tfhe_alloc_trim returns the cached blocks to the driver (drains the device). */
 int tfhe_malloc(size_t bytes, void **dptr);
 int tfhe_free(void *dptr);
+int tfhe_alloc_stats(uint64_t *live_bytes, uint64_t *cached_bytes, uint64_t *hip_mallocs, uint64_t *reuses);
+int tfhe_alloc_trim(void);
 int tfhe_memcpy_h2d(void *dst, const void *src, size_t bytes);  /* synchronous */
 int tfhe_memcpy_d2h(void *dst, const void *src, size_t bytes);  /* synchronous */
 int tfhe_memcpy_d2d(tfhe_ctx *ctx, void *dst, const void *src, size_t bytes); /* on the ctx stream */
@@ -83,6 +90,9 @@ int tfhe_memset(tfhe_ctx *ctx, void *dst, int byte, size_t bytes);
  * <- / -> a batch of single polynomials [count][words] (words = limbs * N), one strided copy on the ctx stream. */
 int tfhe_pack_poly(tfhe_ctx *ctx, uint64_t *packed, const uint64_t *src, int polys, int p, size_t words, int64_t count);
 int tfhe_unpack_poly(tfhe_ctx *ctx, uint64_t *dst, const uint64_t *packed, int polys, int p, size_t words, int64_t count);
+/* dst [count][words] <- src [words] repeated: one ring element (a plaintext operand, a key) against a batch of ciphertexts
+ * (the `Ref(c)` / scalar-broadcast patterns of rlwe_she.jl:143 and ckksencoding.jl:99-124). */
+int tfhe_broadcast_poly(tfhe_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words, int64_t count);
 
 /* ---- K1/K2: nntt / inntt --------------------------------------------------------------------
  * NTT.nntt / NTT.inntt on RingCoeffs (pow2_cyc_rings.jl:295-318), per limb as crt.jl:247-267.

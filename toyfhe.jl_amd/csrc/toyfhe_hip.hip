@@ -20,6 +20,7 @@
 #include "ckks_kernels.h"
 #include "sample_kernels.h"
 #include "ntt_tables.h"
+#include "dev_alloc.h"
 
 namespace {
 
@@ -535,12 +536,14 @@ int tfhe_ctx_create(int64_t N, int L, const uint64_t* q, const uint64_t* psi, tf
             c->num_cus = cus;
     }
     c->own_stream = true;
+    devalloc::register_stream(&c->stream);
     *out = c;
     return TFHE_OK;
 }
 
 int tfhe_ctx_destroy(tfhe_ctx* c) {
     if (!c) return TFHE_OK;
+    devalloc::unregister_stream(&c->stream);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto* t : c->tabs) hipFree(t);
     for (auto* t : c->ksw_allocs) hipFree(t);
@@ -578,11 +581,26 @@ int tfhe_ctx_set_ntt_variant(tfhe_ctx* c, int v) {
 
 int tfhe_malloc(size_t bytes, void** p) {
     if (!p) return fail(TFHE_E_BADARG, "null out pointer");
-    hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+    hipError_t e = devalloc::alloc(bytes, p);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? TFHE_E_NOMEM : TFHE_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     return TFHE_OK;
 }
-int tfhe_free(void* p) { if (p) HIP_TRY(hipFree(p)); return TFHE_OK; }
+int tfhe_free(void* p) { if (p) HIP_TRY(devalloc::release(p)); return TFHE_OK; }
+int tfhe_alloc_stats(uint64_t* live_bytes, uint64_t* cached_bytes, uint64_t* hip_mallocs, uint64_t* reuses) {
+    devalloc::state_t& s = devalloc::S();
+    std::lock_guard<std::mutex> g(s.mu);
+    if (live_bytes) *live_bytes = s.live_bytes;
+    if (cached_bytes) *cached_bytes = s.cached_bytes;
+    if (hip_mallocs) *hip_mallocs = (uint64_t)s.n_hip_malloc;
+    if (reuses) *reuses = (uint64_t)s.n_reuse;
+    return TFHE_OK;
+}
+int tfhe_alloc_trim(void) {
+    devalloc::state_t& s = devalloc::S();
+    std::lock_guard<std::mutex> g(s.mu);
+    devalloc::trim_locked(s);
+    return TFHE_OK;
+}
 int tfhe_memcpy_h2d(void* d, const void* s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return TFHE_OK; }
 int tfhe_memcpy_d2h(void* d, const void* s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return TFHE_OK; }
 int tfhe_memcpy_d2d(tfhe_ctx* c, void* d, const void* s, size_t n) {
@@ -605,6 +623,24 @@ int tfhe_unpack_poly(tfhe_ctx* c, uint64_t* dst, const uint64_t* packed, int pol
     if (count == 0 || words == 0) return TFHE_OK;
     HIP_TRY(hipMemcpy2DAsync(dst, words * 8, packed + (size_t)p * words, (size_t)polys * words * 8, words * 8, (size_t)count,
                              hipMemcpyDeviceToDevice, c->stream));
+    return TFHE_OK;
+}
+// dst[k][:] = src[:] for k < count: one ring element (a plaintext, a key) broadcast over a batch
+__global__ __launch_bounds__(256) void k_broadcast(u64* __restrict__ dst, const u64* __restrict__ src, size_t words) {
+    const size_t w = (size_t)blockIdx.x * 512 + threadIdx.x * 2;
+    if (w + 1 < words) {
+        const ulonglong2 v = *(const ulonglong2*)(src + w);
+        *(ulonglong2*)(dst + (size_t)blockIdx.y * words + w) = v;
+    } else if (w < words) {
+        dst[(size_t)blockIdx.y * words + w] = src[w];
+    }
+}
+int tfhe_broadcast_poly(tfhe_ctx* c, uint64_t* dst, const uint64_t* src, size_t words, int64_t count) {
+    if (!c || !dst || !src) return fail(TFHE_E_BADARG, "null argument");
+    if (count < 0 || count > 65535 || (words & 1)) return fail(TFHE_E_BADARG, "count must be in [0, 65535], words even");
+    if (count == 0 || words == 0) return TFHE_OK;
+    hipLaunchKernelGGL(k_broadcast, dim3((unsigned)((words + 511) / 512), (unsigned)count), dim3(256), 0, c->stream, dst, src, words);
+    HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
 int tfhe_memset(tfhe_ctx* c, void* d, int byte, size_t n) {

@@ -70,6 +70,9 @@ def lib():
         "tfhe_memset": [vp, vp, i32, sz],
         "tfhe_pack_poly": [vp, vp, vp, i32, i32, sz, i64],
         "tfhe_unpack_poly": [vp, vp, vp, i32, i32, sz, i64],
+        "tfhe_broadcast_poly": [vp, vp, vp, sz, i64],
+        "tfhe_alloc_stats": [u64p, u64p, u64p, u64p],
+        "tfhe_alloc_trim": [],
         "tfhe_nntt": [vp, vp, vp, i64, i32, i32p],
         "tfhe_inntt": [vp, vp, vp, i64, i32, i32p],
         "tfhe_add": [vp, vp, vp, vp, i64, i32, i32p],
@@ -115,7 +118,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "tfhe_last_error", "tfhe_device_count", "tfhe_set_device", "tfhe_ctx_create", "tfhe_ctx_destroy", "tfhe_ctx_psi",
     "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
-    "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_pack_poly", "tfhe_unpack_poly", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
+    "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_pack_poly", "tfhe_unpack_poly", "tfhe_broadcast_poly", "tfhe_alloc_stats", "tfhe_alloc_trim", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
     "tfhe_mul", "tfhe_mad", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
     "tfhe_keyswitch", "tfhe_rotate", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
     "tfhe_bfv_plan_set_variant", "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
@@ -137,6 +140,13 @@ def check(rc: int):
     if rc == E_NOMEM:
         raise MemoryError(msg)
     raise HipError(msg)
+
+
+def alloc_stats() -> dict:
+    """live / cached bytes and hipMalloc / reuse counts of the library's recycling allocator (csrc/dev_alloc.h)"""
+    v = [C.c_uint64(0) for _ in range(4)]
+    check(lib().tfhe_alloc_stats(*[C.byref(x) for x in v]))
+    return dict(zip(("live_bytes", "cached_bytes", "hip_mallocs", "reuses"), (x.value for x in v)))
 
 
 def device_count() -> int:

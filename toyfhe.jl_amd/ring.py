@@ -230,13 +230,33 @@ class RingElement:
     def _check(self, o):
         if not isinstance(o, RingElement) or o.ring != self.ring:
             raise UsageError("ring elements belong to different rings")
-        if (o.batch or 1) != (self.batch or 1):
+        if self.batch is not None and o.batch is not None and o.batch != self.batch:
             raise UsageError("ring element batches differ")
+
+    def broadcast_to(self, batch: int) -> "RingElement":
+        """one ring element against a batch (the scalar-broadcast patterns of rlwe_she.jl:143, ckksencoding.jl:99-124):
+        the present domain(s) repeated `batch` times on the device."""
+        assert self.batch is None
+        words = self.ring.L * self.ring.N
+        def rep(b):
+            if b is None:
+                return None
+            out = DeviceBuffer(batch * words)
+            native.check(native.lib().tfhe_broadcast_poly(self.ring.ctx.h, out.ptr, b.ptr, words, batch))
+            return out
+        return RingElement(self.ring, rep(self.primal), rep(self.dual), batch)
+
+    def _align(self, o):
+        """(a, b) with equal batch: an unbatched operand is broadcast against a batched one"""
+        self._check(o)
+        if self.batch == o.batch:
+            return self, o
+        return (self.broadcast_to(o.batch), o) if self.batch is None else (self, o.broadcast_to(self.batch))
 
     def _binary(self, o, op):
         """+ and - , pow2_cyc_rings.jl:192-219: operate in whichever domain(s) both operands have; if the
         domains are disjoint compute both."""
-        self._check(o)
+        self, o = self._align(o)
         ctx, L, idx, n = self.ring.ctx, self.ring.L, self.ring.idx, self.count
         f = ctx.add if op == "+" else ctx.sub
         new_p = new_d = None
@@ -274,7 +294,7 @@ class RingElement:
             if self.dual is not None:
                 d = self._new(); ctx.scalar_mul(scal, self.dual.ptr, d.ptr, n, L, idx)
             return RingElement(self.ring, p, d, self.batch)
-        self._check(o)                               # ring_multiply, pow2_cyc_rings.jl:147-173: dual-only result
+        self, o = self._align(o)                     # ring_multiply, pow2_cyc_rings.jl:147-173: dual-only result
         out = self._new()
         self.ring.ctx.mul(self.coeffs_dual().ptr, o.coeffs_dual().ptr, out.ptr, self.count, self.ring.L, self.ring.idx)
         return RingElement(self.ring, None, out, self.batch)

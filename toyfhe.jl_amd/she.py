@@ -406,8 +406,8 @@ def encrypt_zero(rng, pub: PubKey, batch=None) -> CipherText:
 
 
 def _broadcast(el: RingElement, batch: int) -> RingElement:
-    a = el.to_numpy("dual")
-    return RingElement.from_host(el.ring, np.broadcast_to(a, (batch,) + a.shape).copy(), dual=True)
+    el.coeffs_dual()                                       # keys are used as multiplicands: broadcast the NTT form
+    return RingElement(el.ring, None, el.dual, None).broadcast_to(batch)
 
 
 def encrypt(rng, key, plaintext, scale=None) -> CipherText:
