@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-ntt", action="store_true", help="skip the stand-alone NTT record")
     ap.add_argument("--no-gather", action="store_true", help="skip the timed final gather (multi-rank runs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="ciphertext pairs in the all-core CPU sample (0 = auto)")
+    ap.add_argument("--cabi-gather", action="store_true",
+                    help="time the final gather through the C ABI (tfhe_gather, the library's own RCCL communicator) instead of torch.distributed")
     ap.add_argument("--backend", default=os.environ.get("TFHE_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend; 'gloo' + ranks sharing a GPU is a functional check only")
     return ap.parse_args()
@@ -158,7 +160,12 @@ def main():
     if world > 1 and not args.no_gather:
         import torch.distributed as dist
         flat = out.view(-1)
-        if args.backend == "nccl":
+        comm = None
+        if args.backend == "nccl" and args.cabi_gather:
+            full = torch.empty(world * flat.numel(), dtype=flat.dtype, device=dev)
+            comm = tdist.make_comm()                                   # tfhe_comm_create over the same ranks
+            run_gather = lambda: comm.gather(ctx, flat.data_ptr(), full.data_ptr(), flat.numel())
+        elif args.backend == "nccl":
             full = torch.empty(world * flat.numel(), dtype=flat.dtype, device=dev)
             run_gather = lambda: dist.all_gather_into_tensor(full, flat)
         else:
@@ -172,7 +179,8 @@ def main():
         torch.cuda.synchronize(); tdist.barrier()
         g_s = tdist.max_over_ranks((time.perf_counter() - g0) / greps, device=coll_dev)
         gbytes = flat.numel() * 8 * (world - 1)                        # received per rank
-        gather = {"collective": "all_gather_into_tensor (RCCL over xGMI)" if args.backend == "nccl" else f"{args.backend} functional check",
+        gather = {"collective": ("tfhe_gather (C ABI, ncclAllGather over xGMI)" if comm is not None else "all_gather_into_tensor (RCCL over xGMI)")
+                  if args.backend == "nccl" else f"{args.backend} functional check",
                   "ms_per_step": g_s * 1e3, "bytes_received_per_rank": gbytes, "GBs_per_rank": gbytes / g_s / 1e9,
                   "value_with_gather": B * world / (elapsed / args.steps + g_s)}
         if args.backend == "nccl":

@@ -50,6 +50,7 @@ typedef enum {
 
 typedef struct tfhe_ctx tfhe_ctx;       /* a ring: NegacyclicRing{CRTEncoded{L,...},N} */
 typedef struct tfhe_bfv_plan tfhe_bfv_plan; /* (ℛ, ℛbig, t) of a BFVParams */
+typedef struct tfhe_comm tfhe_comm;     /* the ranks of a multi-GPU job (one process per GPU) */
 
 const char *tfhe_last_error(void);      /* thread-local text of the last failure */
 int tfhe_device_count(int *n);
@@ -189,6 +190,20 @@ int tfhe_bfv_mul_relin(tfhe_bfv_plan *plan, const uint64_t *evk, int n_digits, c
 int tfhe_bfv_plan_set_variant(tfhe_bfv_plan *plan, int variant);
 /* ciphertexts processed per internal chunk (workspace = chunk * (7 nb + 3 ns) * N * 8 bytes); 0 = default (256) */
 int tfhe_bfv_plan_set_chunk(tfhe_bfv_plan *plan, int chunk);
+
+/* ---- multi-GPU: the final gather (the reference is single-process) ---------------------------------------
+ * A batch of independent ciphertexts shards by ciphertext over one process per GPU (contexts and keys replicated, tens of
+ * MiB); nothing is exchanged while computing.  The one optional collective is the gather of per-rank results: an all-gather
+ * over RCCL (xGMI), enqueued on the context's stream.  RCCL is bound at run time (dlopen; TFHE_RCCL_LIB overrides the
+ * library path), so single-GPU use has no RCCL dependency.
+ *   tfhe_comm_id     : rank 0 creates the 128-byte rendezvous id; the host side (MPI.jl / Distributed / torch.distributed)
+ *                      hands it to every rank.
+ *   tfhe_comm_create : collective over the ranks (after tfhe_set_device on each).
+ *   tfhe_gather      : dst [nranks][words_per_rank] <- every rank's src [words_per_rank]; equal shard sizes (pad the last). */
+int tfhe_comm_id(void *id_out /* 128 bytes */);
+int tfhe_comm_create(const void *id, int nranks, int rank, tfhe_comm **out);
+int tfhe_comm_destroy(tfhe_comm *comm);
+int tfhe_gather(tfhe_comm *comm, tfhe_ctx *ctx, const uint64_t *src, uint64_t *dst, size_t words_per_rank);
 
 /* ---- measurement hooks (bench.py): HIP events on the ctx stream --------------------------------
  * While enabled, every NTT kernel launch is bracketed by a pair of events; read returns the number of

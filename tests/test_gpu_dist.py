@@ -49,6 +49,16 @@ start, count = tdist.shard(G, rank, world)
 local = run(c1[start:start + count], c2[start:start + count])
 tdist.barrier()
 parts = tdist.gather_results(local if nccl else local.cpu())
+cabi = None
+if nccl:                                            # tfhe_gather over RCCL on device memory, shards padded to the largest
+    comm = tdist.make_comm()
+    mx = -(-G // world)
+    pad = torch.zeros((mx, 2, ns, N), dtype=torch.int64, device=dev)
+    pad[:count] = local
+    full_d = torch.empty((world, mx, 2, ns, N), dtype=torch.int64, device=dev)
+    comm.gather(ctx, pad.data_ptr(), full_d.data_ptr(), pad.numel())
+    ctx.sync()
+    cabi = torch.cat([full_d[r, :tdist.shard(G, r, world)[1]] for r in range(world)]).cpu().numpy().astype(np.uint64)
 if rank == 0:
     full = torch.cat([x.cpu() for x in parts]).numpy().astype(np.uint64)
     alone = run(c1, c2).cpu().numpy().astype(np.uint64)
@@ -57,6 +67,7 @@ if rank == 0:
     pick = [0, 3, 4, 6]                          # both sides of the shard boundary
     want = rs.keyswitch(ns, False, evk, ref_cpu.bfv_mul(rs, rb, t, c1[pick], c2[pick]))
     print(json.dumps({"same_as_single_rank": bool(np.array_equal(full, alone)), "oracle": bool(np.array_equal(full[pick], want)),
+                      "cabi_gather": None if cabi is None else bool(np.array_equal(cabi, alone)),
                       "counts": [int(x.shape[0]) for x in parts], "backend": "nccl" if nccl else "gloo", "world": world}))
 torch.distributed.destroy_process_group()
 '''
@@ -79,6 +90,25 @@ def test_two_ranks_run_the_engine_on_their_shards():
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["same_as_single_rank"] and res["oracle"] and res["counts"] == [4, 3] and res["world"] == 2
+    assert res["cabi_gather"] in (None, True)        # None on a 1-GPU box (RCCL refuses two ranks on one device)
+
+
+def test_cabi_gather_world_of_one():
+    """tfhe_comm_id / tfhe_comm_create / tfhe_gather with a single rank: RCCL is found and bound at run time, the communicator
+    comes up on this GPU and the all-gather (a copy for one rank) lands on the context's stream."""
+    import numpy as np
+
+    import toyfhe_jl_amd as tf
+    from toyfhe_jl_amd import dist as tdist
+    ctx = tf.Context(64, [tf.nextprime(2**40 + 1, 1, 128)])
+    comm = tdist.make_comm()
+    assert comm.nranks == 1 and comm.rank == 0
+    a = np.arange(1000, dtype=np.uint64)
+    src, dst = tf.DeviceBuffer.from_numpy(a), tf.DeviceBuffer(1000)
+    comm.gather(ctx, src.ptr, dst.ptr, 1000)
+    ctx.sync()
+    assert np.array_equal(dst.to_numpy(), a)
+    comm.close()
 
 
 def test_bench_spawns_the_ranks_it_is_asked_for():

@@ -340,6 +340,34 @@ def test_keyswitch_mixed_modulus_sizes(special):
         assert np.array_equal(dout.to_numpy(want.shape), want), variant
 
 
+@pytest.mark.parametrize("logn,batch", [(14, 6), (15, 3), (16, 2)])
+@pytest.mark.parametrize("special", [True, False])
+def test_keyswitch_mixed_modulus_sizes_large_n(logn, batch, special):
+    """the reference's CKKS ring shape (60-bit q0 and special prime around 40-bit primes, infer.jl:97-107) at N = 2^14 ... 2^16:
+    the fp64-size working limbs take the lift-fused transforms -- their lift reads the 60-bit source limb through the integer
+    path -- and the 60-bit limbs the digit buffer + u64 kernels; 2- and 3-element inputs, centring edges on every limb."""
+    N = 1 << logn
+    qs = H.chain(60, 1, N) + H.chain(40, 3, N) + [H.chain(60, 2, N)[1]]
+    Lk = len(qs)
+    level = Lk - 1 if special else Lk
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(logn * 2 + special)
+    evk = H.uniform_evk(rng, qs, Lk, N)
+    devk = dev(evk)
+    for polys in (2, 3):
+        ct = H.rand_residues(rng, qs[:level], (batch, polys), N)
+        for l in range(level):
+            ct[0, polys - 1, l, :5] = [0, 1, qs[l] - 1, qs[l] // 2, qs[l] // 2 + 1]
+        dct, dout = dev(ct), tf.DeviceBuffer(batch * 2 * level * N)
+        ctx.keyswitch(Lk, level, special, devk.ptr, Lk, dct.ptr, polys, dout.ptr, batch)
+        want = ref.keyswitch(level, special, evk, ct)
+        assert np.array_equal(dout.to_numpy(want.shape), want), polys
+    if logn == 14:                                                    # the all-u64 path must agree
+        ctx.set_ntt_variant(2)
+        ctx.keyswitch(Lk, level, special, devk.ptr, Lk, dct.ptr, 3, dout.ptr, batch)
+        assert np.array_equal(dout.to_numpy(want.shape), want)
+
+
 @pytest.mark.parametrize("N,bits,L,w", [(32, 60, 1, 1), (64, 50, 1, 8), (32, 40, 2, 10), (2048, 50, 3, 16), (16, 61, 4, 32),
                                         (1 << 15, 50, 1, 20)])
 def test_keyswitch_window_matches_oracle(N, bits, L, w):

@@ -5,7 +5,7 @@ The directory name contains a dot, so import it through the repo-root loader mod
 ``native`` (ctypes binding) and the host-side mirror of the reference's ring/ciphertext interface.
 """
 from . import native  # noqa: F401
-from .native import BfvPlan, Context, DeviceBuffer, Event, HipError, UsageError  # noqa: F401
+from .native import BfvPlan, Comm, Context, DeviceBuffer, Event, HipError, UsageError  # noqa: F401
 from . import ring, she  # noqa: F401,E402
 from .ring import NegacyclicRing, RingElement, nextprime  # noqa: F401,E402
 from . import wire  # noqa: F401,E402

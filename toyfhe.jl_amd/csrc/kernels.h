@@ -245,6 +245,7 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_lift(cons
         lf.qi = LT[sel.idx[i]].q;
         lf.half = lf.qi >> 1;
         for (u32 j = 0; j < io.nw; j++) {
+            if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch lifts into this limb
             const u32 tid = fresh_tid();
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qj = Lj.q;
@@ -501,7 +502,6 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
     bool first = true;
     for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
         u32 srow = item, j = item % (u32)sel.n;
-        if (!LIFT && io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
         lift_t lf;
         if constexpr (LIFT) {
             const u32 per_ct = io.level * io.nw, b = item / per_ct, rem = item % per_ct, i = rem / io.nw;
@@ -511,6 +511,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
         }
+        if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         const u64* s = src + ((size_t)srow << (LOGB + 1));
         u64* d = dst + ((size_t)item << (LOGB + 1));
@@ -703,7 +704,6 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
         if (item == ~0u) continue;
         const u32 ph = item & 1u, pl = item >> 1;
         u32 srow = pl, j = pl % (u32)sel.n;
-        if (!LIFT && io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;
         lift_t lf;
         if constexpr (LIFT) {
             const u32 per_ct = io.level * io.nw, b = pl / per_ct, rem = pl % per_ct, i = rem / io.nw;
@@ -713,6 +713,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
         }
+        if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         const u64* s = src + srow * ntot;
         u64* d = dst + pl * ntot + brev_bits(ph, x);
@@ -1560,9 +1561,10 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
 // RNS digits as a separate pass (only for N > 2^14, where the lift is not fused into the NTT loads):
 // dig [batch][level][nw][N]; digit i, limb j = centred([c_end]_{q_i}) mod q_w[j]  (rlwe_she.jl:326-329)
 __global__ __launch_bounds__(256) void k_ks_digits(const u64* __restrict__ ct, u64* __restrict__ dig,
-                                                    const ntt_limb_t* __restrict__ LT, ks_arg_t A, u32 n) {
+                                                    const ntt_limb_t* __restrict__ LT, ks_arg_t A, u32 n, u32 limb_mask) {
     const u32 row = blockIdx.x, j = row % (u32)A.nw, i = (row / (u32)A.nw) % (u32)A.level,
               b = row / ((u32)A.nw * (u32)A.level);
+    if (limb_mask && !((limb_mask >> j) & 1u)) return;  // the lift-fused fp64 transforms take this working limb
     lift_t lf;
     lf.qi = LT[A.w.idx[i]].q; lf.half = lf.qi >> 1; lf.qj = LT[A.w.idx[j]].q; lf.bj = LT[A.w.idx[j]].br;
     const u64* c = ct + (((size_t)b * A.polys + (A.polys - 1)) * A.level + i) * n;

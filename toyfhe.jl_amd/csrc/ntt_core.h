@@ -108,6 +108,7 @@ struct ntt_limb_t {   // per-limb constants (device copy lives in the context)
     // boundary pass of each half permuted within its half of every stage block
 };
 
+// (ArithFpWide, the fp64 policy for digit lifts out of source limbs above 2^52, is defined after ArithFp below.)
 // Progress hook of the butterfly loops: called after every twiddle group with the number of butterflies of the
 // pass done before / after it and the pass total.  The staged kernels use it to spread memory instructions
 // (LDS-DMA of the next row, stores of the previous one) through the arithmetic instead of issuing them in a clump.
@@ -249,6 +250,20 @@ struct ArithFp {
     static TFHE_HD u64 out_fwd(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
     static TFHE_HD u64 out_inv_scaled(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
     static TFHE_HD u64 out_inv_lazy(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
+};
+// The fp64 policy for digit lifts whose SOURCE limb may be above 2^52 (the 60-bit q0 of the reference's CKKS rings next to
+// its 40-bit primes, infer.jl:98-107): such a residue does not fit a double, so that digit is centred and reduced in
+// integers (lift_digit) and enters as the centred double of its canonical residue; the choice is uniform over the item (one
+// source limb per row).  A separate policy type, so that the kernels of uniform fp64 rings keep their branch-free first
+// pass (a run-time branch next to a load phase costs them a third of their rate).
+struct ArithFpWide : ArithFp {
+    static TFHE_HD elem from_global_lift(u64 x, const ctx& c, const lift_t& f, bool loose = false) {
+        if (f.qi >> 52) {
+            const double r = fp_from_u64(lift_digit(x, f));
+            return r + r > c.p ? r - c.p : r;
+        }
+        return ArithFp::from_global_lift(x, c, f, loose);
+    }
 };
 
 // Optional transforms fused into the block kernels' global I/O (key switching, src/rlwe_she.jl:326-344):

@@ -269,7 +269,7 @@ int launch_generic(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t 
 // out-of-place intermediate), or the one-kernel variants of the fp64 policy.  io.limb_mask restricts every kernel of the
 // call to those limbs (rings that mix modulus sizes: one call per policy).
 int run_ntt_large(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, const ntt_io_t& io,
-                  const ntt_io_t* iop, bool fp) {
+                  const ntt_io_t* iop, bool fp, bool wide_lift = false) {
     const int n = c->logN, x = n - 14;
     const bool pair15 = x == 1 && c->variant == 0 && fp;
     if (iop && x == 1 && !(pair15 && !inverse && io.mode == 1))
@@ -282,6 +282,7 @@ int run_ntt_large(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t r
         if (!pattr_set) {
             int rc2 = set_lds(k_ntt_fwd_pair<ArithFp, 14, LOGT>, lds);
             if (!rc2) rc2 = set_lds(k_ntt_fwd_pair<ArithFp, 14, LOGT, true>, lds);
+            if (!rc2) rc2 = set_lds(k_ntt_fwd_pair<ArithFpWide, 14, LOGT, true>, lds);
             if (!rc2) rc2 = set_lds(k_ntt_inv_pair<ArithFp, 14, LOGT>, lds);
             if (rc2) return rc2;
             pattr_set = true;
@@ -289,6 +290,7 @@ int run_ntt_large(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t r
         const unsigned grid = std::min((unsigned)rows, (unsigned)c->num_cus);
         prof_begin(c, rows);
         if (inverse) hipLaunchKernelGGL((k_ntt_inv_pair<ArithFp, 14, LOGT>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows, io.limb_mask);
+        else if (io.mode == 1 && wide_lift) hipLaunchKernelGGL((k_ntt_fwd_pair<ArithFpWide, 14, LOGT, true>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows, io);
         else if (io.mode == 1) hipLaunchKernelGGL((k_ntt_fwd_pair<ArithFp, 14, LOGT, true>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows, io);
         else hipLaunchKernelGGL((k_ntt_fwd_pair<ArithFp, 14, LOGT>), dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, (u32)rows, io);
         prof_end(c);
@@ -305,10 +307,12 @@ int run_ntt_large(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t r
         // row's other workgroup reads the same source words)
         constexpr int LOGT = logt_for(14);
         const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
-        auto qk = io.mode == 1 ? k_ntt_fwd_quad<ArithFp, 14, LOGT, true> : k_ntt_fwd_quad<ArithFp, 14, LOGT, false>;
+        auto qk = io.mode == 1 ? (wide_lift ? k_ntt_fwd_quad<ArithFpWide, 14, LOGT, true> : k_ntt_fwd_quad<ArithFp, 14, LOGT, true>)
+                               : k_ntt_fwd_quad<ArithFp, 14, LOGT, false>;
         static bool qattr_set = false;
         if (!qattr_set) {
             int rc2 = set_lds(k_ntt_fwd_quad<ArithFp, 14, LOGT, true>, lds);
+            if (!rc2) rc2 = set_lds(k_ntt_fwd_quad<ArithFpWide, 14, LOGT, true>, lds);
             if (!rc2) rc2 = set_lds(k_ntt_fwd_quad<ArithFp, 14, LOGT, false>, lds);
             if (rc2) return rc2;
             qattr_set = true;
@@ -364,16 +368,31 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
     if (n <= 14) {
         const bool fp = sel_fp(c, sel, 0);
         // a ring that mixes fp64-size moduli with larger ones (60-bit q0 / special prime next to 40-bit primes): one launch
-        // per policy, each taking its limbs (ntt_io_t::limb_mask); the digit-lift mode reads source limbs of either size and
-        // stays on the u64 kernels
+        // per policy, each taking its limbs (ntt_io_t::limb_mask)
         u32 fpmask = 0;
         for (int j = 0; j < sel.n; j++)
             if (c->limbs_host[sel.idx[j]].Wd) fpmask |= 1u << j;
         const u32 all = sel.n >= 32 ? ~0u : ((1u << sel.n) - 1u);
-        if (!fp && c->variant == 0 && fpmask != 0 && fpmask != all && io.mode != 1 && (rows << n) >= TFHE_MIXED_MIN_WORDS) {
+        if (!fp && c->variant == 0 && fpmask != 0 && fpmask != all && (io.mode != 1 || n >= 12) && (rows << n) >= TFHE_MIXED_MIN_WORDS) {
+            // (digit-lift mode: the mask is on the TARGET limb j of item (b, i, j); the fp64 lift takes source limbs of either
+            // size through ArithFpWide, instantiated for N >= 2^12)
             ntt_io_t a = io, b = io;
             a.limb_mask = fpmask;
             b.limb_mask = all & ~fpmask;
+            if (io.mode == 1) {
+                int rc1 = TFHE_E_UNSUPPORTED;
+                switch (n) {
+                    case 12: rc1 = launch_block_fwd<ArithFpWide, 12, 1>(c, src, dst, rows, sel, 0, a); break;
+                    case 13: rc1 = launch_block_fwd<ArithFpWide, 13, 1>(c, src, dst, rows, sel, 0, a); break;
+                    case 14: rc1 = launch_block_fwd<ArithFpWide, 14, 1>(c, src, dst, rows, sel, 0, a); break;
+                }
+                if (rc1) return rc1;
+                switch (n) {
+                    case 12: return launch_block_fwd<ArithInt, 12, 1>(c, src, dst, rows, sel, 0, b);
+                    case 13: return launch_block_fwd<ArithInt, 13, 1>(c, src, dst, rows, sel, 0, b);
+                    default: return launch_block_fwd<ArithInt, 14, 1>(c, src, dst, rows, sel, 0, b);
+                }
+            }
             switch (n) {
 #define CASE_(LB)                                                                                                  \
     case LB: {                                                                                                     \
@@ -840,14 +859,34 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
     }
     const bool lift_fused = c->logN <= 14 || ((c->logN == 15 || c->logN == 16) && c->variant == 0 && sel_fp(c, A.w, c->logN - 14) &&
                                               (((uintptr_t)ct | (uintptr_t)dig) & 15u) == 0);
+    // rings that mix fp64-size moduli with larger ones (infer.jl:97-112: 60-bit q0 and special prime next to 40-bit primes)
+    // at N = 2^15 / 2^16: the fp64-size working limbs take the lift-fused one-kernel transforms (the fp64 lift reads source
+    // limbs of either size), the others go through the digit buffer and the u64 kernels
+    u32 fpmask = 0;
+    for (int j = 0; j < nw; j++)
+        if (c->limbs_host[A.w.idx[j]].Wd) fpmask |= 1u << j;
+    const u32 allmask = (1u << nw) - 1u;
+    const bool lift_mixed = !lift_fused && (c->logN == 15 || c->logN == 16) && c->variant == 0 && fpmask != 0 && fpmask != allmask &&
+                            (((uintptr_t)ct | (uintptr_t)dig) & 15u) == 0;
     if (lift_fused) {
         // digits: centred lift of limb i of c[end] into every working limb, fused into the forward NTT's loads
         ntt_io_t io = io_plain();
         io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys;
         rc = run_ntt(c, false, ct, dig, batch * level * nw, A.w, &io);
         if (rc) return rc;
+    } else if (lift_mixed) {
+        ntt_io_t io = io_plain();
+        io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys; io.limb_mask = fpmask;
+        rc = run_ntt_large(c, false, ct, dig, batch * level * nw, A.w, io, &io, true, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_ks_digits, row_grid((unsigned)(batch * level * nw), (size_t)c->N), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n, allmask & ~fpmask);
+        HIP_TRY(hipGetLastError());
+        ntt_io_t iw = io_plain();
+        iw.limb_mask = allmask & ~fpmask;
+        rc = run_ntt_large(c, false, dig, dig, batch * level * nw, A.w, iw, nullptr, false);
+        if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(k_ks_digits, row_grid((unsigned)(batch * level * nw), (size_t)c->N), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n);
+        hipLaunchKernelGGL(k_ks_digits, row_grid((unsigned)(batch * level * nw), (size_t)c->N), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n, 0u);
         HIP_TRY(hipGetLastError());
         rc = run_ntt(c, false, dig, dig, batch * level * nw, A.w);
         if (rc) return rc;
@@ -1263,3 +1302,4 @@ int tfhe_event_elapsed_ms(void* a, void* b, float* ms) {
 }  // extern "C"
 
 #include "bfv_api.inc"
+#include "comm_api.inc"

@@ -68,3 +68,26 @@ def gather_results(local, dst: int = 0):
     if rank != dst:
         return None
     return [b[: int(c.item())] for b, c in zip(bufs, counts)]
+
+
+def make_comm():
+    """tfhe_comm over this job's ranks (the C-ABI gather boundary, include/toyfhe_hip.h): rank 0's RCCL rendezvous id is
+    broadcast with torch.distributed (any backend), then every rank joins.  World size 1 works without a process group."""
+    import torch
+    import torch.distributed as dist
+
+    from . import native
+    world, rank, _ = env_world()
+    if not (dist.is_available() and dist.is_initialized()):
+        world, rank = 1, 0
+
+    def exchange(data):
+        if world == 1:
+            return data
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.zeros(128, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+        dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+    return native.Comm(world, rank, exchange)

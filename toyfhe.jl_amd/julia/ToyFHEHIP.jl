@@ -382,4 +382,26 @@ function device_count()
     n = Ref{Cint}(0); check(ccall((:tfhe_device_count, lib), Cint, (Ptr{Cint},), n)); Int(n[])
 end
 
+# rank 0 makes the RCCL rendezvous id (tfhe_comm_id) and hands it to the other ranks through the host-side transport
+# (MPI.bcast, Distributed.remotecall ...); every rank then joins.  gather!: all-gather of equally sized per-rank shards.
+mutable struct HipComm
+    handle::Ptr{Cvoid}; nranks::Int; rank::Int
+end
+function comm_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:tfhe_comm_id, lib), Cint, (Ptr{Cvoid},), id)); id
+end
+function HipComm(id::Vector{UInt8}, nranks::Integer, rank::Integer)
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:tfhe_comm_create, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}), id, nranks, rank, h))
+    c = HipComm(h[], nranks, rank)
+    finalizer(x -> ccall((:tfhe_comm_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), c)
+    c
+end
+function gather!(comm::HipComm, ring::HipRing, dst::HipVector, src::HipVector)
+    check(ccall((:tfhe_gather, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Csize_t),
+                comm.handle, ring.handle, src.ptr, dst.ptr, words(src)))
+    dst
+end
+
 end # module

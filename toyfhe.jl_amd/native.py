@@ -43,6 +43,30 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so and loads it by file name, so an
+    engine that was loaded first (against /opt/rocm's copy, same SONAME) would leave the process with two runtimes whose
+    streams and allocations do not mix (torch streams passed to tfhe_ctx_set_stream, RCCL from torch/lib).  If such a wheel
+    is installed and not yet imported, load ITS runtime first: the engine's NEEDED libamdhip64.so.7 then resolves to it, and
+    a later `import torch` shares it.  TFHE_USE_SYSTEM_HIP=1 skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("TFHE_USE_SYSTEM_HIP", "0") not in ("", "0"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _LIB
     if _LIB is not None:
@@ -50,6 +74,7 @@ def lib():
     if not os.path.exists(_SO):
         raise HipError(f"{_SO} is missing: the HIP engine was not built "
                        "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    _one_hip_runtime()
     L = C.CDLL(_SO)
     L.tfhe_last_error.restype = C.c_char_p
     vp, i64, i32, u64, sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_size_t
@@ -73,6 +98,10 @@ def lib():
         "tfhe_broadcast_poly": [vp, vp, vp, sz, i64],
         "tfhe_alloc_stats": [u64p, u64p, u64p, u64p],
         "tfhe_alloc_trim": [],
+        "tfhe_comm_id": [vp],
+        "tfhe_comm_create": [vp, i32, i32, C.POINTER(vp)],
+        "tfhe_comm_destroy": [vp],
+        "tfhe_gather": [vp, vp, vp, vp, sz],
         "tfhe_nntt": [vp, vp, vp, i64, i32, i32p],
         "tfhe_inntt": [vp, vp, vp, i64, i32, i32p],
         "tfhe_add": [vp, vp, vp, vp, i64, i32, i32p],
@@ -118,7 +147,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "tfhe_last_error", "tfhe_device_count", "tfhe_set_device", "tfhe_ctx_create", "tfhe_ctx_destroy", "tfhe_ctx_psi",
     "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
-    "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_pack_poly", "tfhe_unpack_poly", "tfhe_broadcast_poly", "tfhe_alloc_stats", "tfhe_alloc_trim", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
+    "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_pack_poly", "tfhe_unpack_poly", "tfhe_broadcast_poly", "tfhe_alloc_stats", "tfhe_alloc_trim", "tfhe_comm_id", "tfhe_comm_create", "tfhe_comm_destroy", "tfhe_gather", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
     "tfhe_mul", "tfhe_mad", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
     "tfhe_keyswitch", "tfhe_rotate", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
     "tfhe_bfv_plan_set_variant", "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
@@ -340,6 +369,34 @@ class BfvPlan:
 
     def mul_relin(self, evk, n_digits, c1, c2, out, batch):
         check(lib().tfhe_bfv_mul_relin(self.h, evk, n_digits, c1, c2, out, batch))
+
+
+class Comm:
+    """The ranks of a multi-GPU job for the final gather (tfhe_comm over RCCL).  `exchange(id_bytes_or_None) -> id_bytes` is
+    the host-side broadcast of rank 0's rendezvous id (torch.distributed, MPI, a file ...)."""
+
+    def __init__(self, nranks: int, rank: int, exchange):
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            check(lib().tfhe_comm_id(buf))
+        data = exchange(bytes(buf.raw) if rank == 0 else None)
+        h = C.c_void_p()
+        check(lib().tfhe_comm_create(C.create_string_buffer(data, 128), nranks, rank, C.byref(h)))
+        self.h, self.nranks, self.rank = h.value, nranks, rank
+
+    def gather(self, ctx: "Context", src_ptr: int, dst_ptr: int, words_per_rank: int):
+        check(lib().tfhe_gather(self.h, ctx.h, src_ptr, dst_ptr, words_per_rank))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().tfhe_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Event:
