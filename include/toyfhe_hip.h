@@ -139,6 +139,20 @@ int tfhe_keyswitch(tfhe_ctx *ctx, int key_limbs, int level, int special, const u
 /* rotate(gk, c) = keyswitch(gk, apply_galois_element(c, g)) (rlwe_she.jl:355-359) */
 int tfhe_rotate(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint64_t *evk, int n_digits, uint64_t galois_element, const uint64_t *ct, uint64_t *out, int64_t batch);
 
+/* Hoisted rotations: out[r] = rotate(gk_r, c) for r < n_rot from one digit decomposition of c (the RNS digits commute with
+ * the automorphism; in the NTT domain it is an index permutation), bit-identical to n_rot calls of tfhe_rotate at
+ * level * (level [+1]) forward transforms in total instead of per rotation -- the shape of a diagonal-method matrix product
+ * (ckks_matmul.jl:33-41, infer.jl:140-149) when every rotation starts from the same ciphertext.
+ *   evks: HOST array of n_rot device pointers (one Galois key each, layout as tfhe_keyswitch; prepared != 0: the outputs of
+ *   tfhe_galois_key_prepare); galois: HOST array [n_rot];
+ *   ct: [batch][2][level][N]; out: [n_rot][batch][2][level][N]. */
+int tfhe_rotate_many(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint64_t *const *evks, int n_digits, int prepared,
+                     const uint64_t *galois_elements, int n_rot, const uint64_t *ct, uint64_t *out, int64_t batch);
+/* the one-time key preparation of the hoisted rotations: evk_out = the Galois key of x -> x^g (layout of tfhe_keyswitch,
+ * n_digits components over key_limbs moduli) with every NTT-domain row permuted by g^-1, so that the key products run on the
+ * transformed digits of the unrotated ciphertext.  prepared = 0 above takes plain keys and prepares them per call. */
+int tfhe_galois_key_prepare(tfhe_ctx *ctx, int key_limbs, int n_digits, uint64_t galois_element, const uint64_t *evk, uint64_t *evk_out);
+
 /* ---- K14: keyswitch with base-2^w digits (relin_window = w != 0, rlwe_she.jl:330-338; the default for
  * single-modulus rings, rlwe_she.jl:271) -------------------------------------------------------------
  * The ring is limbs 0..level-1 of ctx (no special prime).  Digit i of a coefficient is digit i of

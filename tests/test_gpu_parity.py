@@ -402,6 +402,49 @@ def test_keyswitch_window_matches_oracle(N, bits, L, w):
         ctx.keyswitch_window(L, w, devk.ptr, nwin, devk.ptr, 4, devk.ptr, 1)           # rlwe_she.jl:318
 
 
+@pytest.mark.parametrize("N,qspec,batch", [(2048, "60x3", 3), (1 << 12, "mixed", 40), (1 << 14, "50x4", 5), (1 << 15, "50x3", 2),
+                                           (1 << 16, "50x3", 2), (1 << 16, "mixed", 2)])
+@pytest.mark.parametrize("special", [True, False])
+def test_rotate_many_equals_individual_rotations(N, qspec, batch, special):
+    """tfhe_rotate_many (hoisted rotations: one digit decomposition, the automorphism applied as an index permutation of the
+    transformed digits) against tfhe_rotate per Galois element, bit for bit, and one of them against the oracle."""
+    if qspec == "mixed":
+        qs = H.chain(60, 1, N) + H.chain(40, 2, N) + [H.chain(60, 2, N)[1]]
+    else:
+        bits, n = qspec.split("x")
+        qs = H.chain(int(bits), int(n), N)
+    Lk = len(qs)
+    level = Lk - 1 if special else Lk
+    ctx, ref = tf.Context(N, qs), ref_cpu.RefCtx(N, qs)
+    rng = np.random.default_rng(N % 1000 + special)
+    gs = [3, pow(3, 2 * N - 1, 2 * N), 2 * N - 1, pow(3, 5, 2 * N)]
+    evks = [H.uniform_evk(rng, qs, Lk, N) for _ in gs]
+    devks = [dev(e) for e in evks]
+    ct = H.rand_residues(rng, qs[:level], (batch, 2), N)
+    for l in range(level):
+        ct[0, 1, l, :5] = [0, 1, qs[l] - 1, qs[l] // 2, qs[l] // 2 + 1]
+    dct = dev(ct)
+    out = tf.DeviceBuffer(len(gs) * batch * 2 * level * N)
+    ctx.rotate_many(Lk, level, special, [d.ptr for d in devks], Lk, gs, dct.ptr, out.ptr, batch)
+    got = out.to_numpy((len(gs), batch, 2, level, N))
+    one = tf.DeviceBuffer(batch * 2 * level * N)
+    for r, g in enumerate(gs):
+        ctx.rotate(Lk, level, special, devks[r].ptr, Lk, g, dct.ptr, one.ptr, batch)
+        assert np.array_equal(got[r], one.to_numpy((batch, 2, level, N))), (r, g)
+    r = 1
+    want = ref.keyswitch(level, special, evks[r], ref.galois(gs[r], ct.reshape(-1, level, N), idx=range(level)).reshape(ct.shape))
+    assert np.array_equal(got[r], want)
+    # prepared keys (rows permuted by g^-1 once) give the same bits
+    prep = [tf.DeviceBuffer(e.size) for e in evks]
+    for r, g in enumerate(gs):
+        ctx.galois_key_prepare(Lk, Lk, g, devks[r].ptr, prep[r].ptr)
+    out2 = tf.DeviceBuffer(len(gs) * batch * 2 * level * N)
+    ctx.rotate_many(Lk, level, special, [d.ptr for d in prep], Lk, gs, dct.ptr, out2.ptr, batch, prepared=True)
+    assert np.array_equal(out2.to_numpy(got.shape), got)
+    with pytest.raises(AssertionError):
+        ctx.rotate_many(Lk, level, special, [devks[0].ptr], Lk, [4], dct.ptr, out.ptr, batch)   # even element
+
+
 @pytest.mark.parametrize("special", [False, True])
 def test_rotate_full_degree_matches_oracle(special):
     """rotate = keyswitch o apply_galois_element (rlwe_she.jl:355-359) at N = 2^14 -- the fused key-switch kernel behind the

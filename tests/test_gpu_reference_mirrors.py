@@ -162,3 +162,32 @@ def test_ckks_triv():
     cc = c * c
     assert len(cc) == 3
     assert np.allclose(tf.ckks_decode(tf.decrypt(kp, cc), cc.scale).real, x**2, atol=1e-4)  # :32
+
+
+def test_matmul_by_hoisted_rotations():
+    """the diagonal-method product of ckks_matmul.jl:33-41 / infer.jl:140-149 with every rotation taken from the SAME ciphertext
+    (one Galois key per step, tf.rotate_many: one digit decomposition for all of them) -- each rotation bit-identical to
+    rotate(gk_k, c), the product within the test's tolerance."""
+    N = 64
+    R = tf.NegacyclicRing(N, chain(2**40 + 1, 4, N))
+    params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    rng = np.random.default_rng(13)
+    kp = tf.keygen(rng, params)
+    scale = 2**40
+    n = 8                                                                       # 8 x 8 matrix, 4 copies side by side in the 32 slots
+    x = rng.normal(0, 1, N // 2)
+    W = rng.normal(0, 1, (n, n))
+    c = tf.encrypt(rng, kp, tf.ckks_encode(x.astype(complex), params.R_cipher(), scale), scale=scale)
+    B = N // 2 // n
+    gks = [tf.keygen_galois(rng, kp.priv, steps=k * B) for k in range(1, n)]
+    rots = tf.rotate_many(gks, c)
+    for gk, r in zip(gks, rots):                                                # bit-identical to the one-at-a-time rotation
+        one = tf.rotate(gk, c)
+        assert all(np.array_equal(a.to_numpy(), b.to_numpy()) for a, b in zip(r.cs, one.cs))
+    diag = lambda k: np.repeat(np.array([W[i, (i - k) % n] for i in range(n)]), B)
+    res = c.mul_plain(diag(0))
+    for k in range(1, n):
+        res = res + rots[k - 1].mul_plain(diag(k))
+    got = tf.ckks_decode(tf.decrypt(kp, res), res.scale).real.reshape(n, B)
+    want = W @ x.reshape(n, B)
+    assert np.allclose(got, want, atol=1e-5)

@@ -1052,6 +1052,17 @@ __global__ __launch_bounds__(256) void k_galois(const u64* __restrict__ src, u64
 // ------------------------------------------------------------------------------------------------
 // keyswitch pieces (rlwe_she.jl:315-347, modulusraising.jl:35-49)
 // ------------------------------------------------------------------------------------------------
+// NTT-domain action of the Galois automorphism x -> x^g (pow2_cyc_rings.jl:321-329) in the library's natural order
+// a^[k] = a(psi^(2k+1)):  (sigma_g a)^[k] = a(psi^(g (2k+1))) = a^[k'] with 2k' + 1 = g (2k+1) mod 2N -- a pure permutation.
+TFHE_HD u32 galois_ntt_pos(u32 k, u64 g, u32 n) { return (u32)(((g * (2ull * k + 1ull)) - 1ull) >> 1) & (n - 1u); }
+
+// dst[row][m] = src[row][pi_g(m)]: the automorphism applied to NTT-domain rows (key preparation of the hoisted rotations)
+__global__ __launch_bounds__(256) void k_ntt_perm(const u64* __restrict__ src, u64* __restrict__ dst, u64 g, u32 n) {
+    const u64* s = src + (size_t)blockIdx.x * n;
+    u64* d = dst + (size_t)blockIdx.x * n;
+    for (u32 m = blockIdx.y * blockDim.x + threadIdx.x; m < n; m += gridDim.y * blockDim.x) d[m] = s[galois_ntt_pos(m, g, n)];
+}
+
 struct ks_arg_t {
     int level, nw, special, polys;
     limb_sel_t w;                // working limbs: key limbs 0..level-1 (+ special prime)

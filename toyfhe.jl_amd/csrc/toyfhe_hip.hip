@@ -790,6 +790,133 @@ static bool ks_prelift_ok(const tfhe_ctx* c, int level) {
     for (int j = 0; j < level; j++) { lo = std::min(lo, c->q[j]); hi = std::max(hi, c->q[j]); }
     return hi <= 2 * lo;
 }
+// Part A of the unfused key switch: the NTT-domain RNS digits of c[end], dig [batch][level][nw][N]
+// (centred lift of limb i into every working limb, rlwe_she.jl:326-329, then forward transforms).
+static int ks_digits_fwd(tfhe_ctx* c, const ks_arg_t& A, const u64* ct, u64* dig, int64_t batch) {
+    const int level = A.level, nw = A.nw, polys = A.polys;
+    const u32 n = (u32)c->N;
+    int rc;
+    const bool lift_fused = c->logN <= 14 || ((c->logN == 15 || c->logN == 16) && c->variant == 0 && sel_fp(c, A.w, c->logN - 14) &&
+                                              (((uintptr_t)ct | (uintptr_t)dig) & 15u) == 0);
+    // rings that mix fp64-size moduli with larger ones (infer.jl:97-112: 60-bit q0 and special prime next to 40-bit primes)
+    // at N = 2^15 / 2^16: the fp64-size working limbs take the lift-fused one-kernel transforms (the fp64 lift reads source
+    // limbs of either size), the others go through the digit buffer and the u64 kernels
+    u32 fpmask = 0;
+    for (int j = 0; j < nw; j++)
+        if (c->limbs_host[A.w.idx[j]].Wd) fpmask |= 1u << j;
+    const u32 allmask = (1u << nw) - 1u;
+    const bool lift_mixed = !lift_fused && (c->logN == 15 || c->logN == 16) && c->variant == 0 && fpmask != 0 && fpmask != allmask &&
+                            (((uintptr_t)ct | (uintptr_t)dig) & 15u) == 0;
+    if (lift_fused) {
+        // digits: centred lift of limb i of c[end] into every working limb, fused into the forward NTT's loads
+        ntt_io_t io = io_plain();
+        io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys;
+        rc = run_ntt(c, false, ct, dig, batch * level * nw, A.w, &io);
+        if (rc) return rc;
+    } else if (lift_mixed) {
+        ntt_io_t io = io_plain();
+        io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys; io.limb_mask = fpmask;
+        rc = run_ntt_large(c, false, ct, dig, batch * level * nw, A.w, io, &io, true, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_ks_digits, row_grid((unsigned)(batch * level * nw), (size_t)c->N), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n, allmask & ~fpmask);
+        HIP_TRY(hipGetLastError());
+        ntt_io_t iw = io_plain();
+        iw.limb_mask = allmask & ~fpmask;
+        rc = run_ntt_large(c, false, dig, dig, batch * level * nw, A.w, iw, nullptr, false);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k_ks_digits, row_grid((unsigned)(batch * level * nw), (size_t)c->N), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n, 0u);
+        HIP_TRY(hipGetLastError());
+        rc = run_ntt(c, false, dig, dig, batch * level * nw, A.w);
+        if (rc) return rc;
+    }
+    return TFHE_OK;
+}
+
+static int do_galois(tfhe_ctx* c, const u64* src, u64* dst, u64 g, int64_t rows, const limb_sel_t& sel);
+// Part B: S_s = sum_i evk_{i,s} (.) digit_i, inverse transforms, and the tail out_s = ct_s + ... (with the special prime: the
+// ModulusRaised contraction).  `ct` only supplies the addends.  `tbuf` ([batch][2][nw][N]) receives the sub-block inverse at
+// N = 2^16; the plain key switch passes the digit buffer (free by then).
+// Hoisted rotations (g != 0): `evk` is the key of x -> x^g prepared by tfhe_galois_key_prepare (its NTT-domain rows permuted by
+// g^-1), so the sums are those of the rotated digits up to that permutation: S' = sigma_g^-1(S).  The automorphism is applied
+// to INTT(S') in the coefficient domain (a signed permutation) BEFORE the tail -- the ModulusRaised floor does not commute
+// with sign changes -- into `tbuf`, which must not alias the digits (they are reused by the next rotation).
+static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, const u64* ct, u64* out, int64_t batch, u64* S,
+                     const u64* dig, u64* tbuf, u64 g) {
+    const int level = A.level, nw = A.nw, polys = A.polys, special = A.special;
+    const u32 n = (u32)c->N;
+    const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
+    int rc;
+    const unsigned gx = (n + 255) / 256;
+    // enough workgroups to fill the chip: split the batch into slices (the key is re-read once per slice)
+    const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx - 1) / (nw * gx)));
+    bool narrow = (n % 2 == 0);
+    for (int j = 0; j < nw; j++) narrow = narrow && (c->limbs_host[A.w.idx[j]].q >> 52) == 0;
+    if (narrow) {
+        const unsigned gx2 = (n / 2 + 255) / 256;
+        const unsigned bs2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx2 - 1) / (nw * gx2)));
+        hipLaunchKernelGGL(k_ks_inner_n2<8>, dim3((unsigned)nw * gx2 * bs2), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2);
+    } else {
+        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit);
+    }
+    HIP_TRY(hipGetLastError());
+    if (g != 0) {  // hoisted rotation: INTT, automorphism, tail
+        rc = run_ntt(c, true, S, S, batch * 2 * nw, A.w);
+        if (rc) return rc;
+        rc = do_galois(c, S, tbuf, g, batch * 2 * nw, A.w);
+        if (rc) return rc;
+        if (special) {
+            rescale_arg_t ra;
+            memset(&ra, 0, sizeof ra);
+            const u64 P = c->q[Lk - 1];
+            for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+            hipLaunchKernelGGL(k_ks_rescale_add, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, tbuf, ct, out, c->limbs_dev, A, ra, n, add_s);
+        } else {
+            HIP_TRY(hipMemcpyAsync(out, tbuf, (size_t)batch * 2 * level * c->N * 8, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_ks_add_ct, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, ct, out, c->limbs_dev, A, n, add_s);
+        }
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
+    if (c->logN == 16 && c->variant == 0 && sel_fp(c, A.w, 2) && level >= 2 && (((uintptr_t)S | (uintptr_t)tbuf) & 15u) == 0) {
+        // N = 2^16: the paired sub-block inverse into the (now free) digit buffer, then the two inverse top stages together with
+        // the tail (k_ks_top_tail<2>) instead of k_ntt_inv_top<2> + k_ks_rescale_add / k_ks_add_ct
+        rc = launch_subpair<ArithFp>(c, true, S, tbuf, batch * 2 * nw, A.w, 2, 0u);
+        if (rc) return rc;
+        rescale_arg_t ra;
+        memset(&ra, 0, sizeof ra);
+        if (special) {
+            const u64 P = c->q[Lk - 1];
+            for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+        }
+        hipLaunchKernelGGL(k_ks_top_tail<2>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 4), dim3(256), 0, c->stream, tbuf, ct, out, c->limbs_dev, A, ra, n, add_s);
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
+    if (special) {
+        rc = run_ntt(c, true, S, S, batch * 2 * nw, A.w);
+        if (rc) return rc;
+        rescale_arg_t ra;
+        memset(&ra, 0, sizeof ra);
+        const u64 P = c->q[Lk - 1];
+        for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+        hipLaunchKernelGGL(k_ks_rescale_add, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
+    if (c->logN <= 14) {  // out = c + INTT(S), the addition fused into the inverse NTT's stores
+        ntt_io_t io = io_plain();
+        io.mode = 2; io.gsz = (u32)(2 * level); io.src_gstride = io.gsz; io.dst_gstride = io.gsz;
+        io.add_rows = add_s * (u32)level; io.add_gstride = (u32)(polys * level); io.addend = ct;
+        return run_ntt(c, true, S, out, batch * 2 * nw, A.w, &io);
+    }
+    rc = run_ntt(c, true, S, out, batch * 2 * nw, A.w);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ks_add_ct, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, ct, out, c->limbs_dev, A, n, add_s);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
 static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
                     u64* S, u64* dig, const u64* evd, bool prelifted) {
     const int nw = special ? level + 1 : level;
@@ -857,90 +984,9 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
-    const bool lift_fused = c->logN <= 14 || ((c->logN == 15 || c->logN == 16) && c->variant == 0 && sel_fp(c, A.w, c->logN - 14) &&
-                                              (((uintptr_t)ct | (uintptr_t)dig) & 15u) == 0);
-    // rings that mix fp64-size moduli with larger ones (infer.jl:97-112: 60-bit q0 and special prime next to 40-bit primes)
-    // at N = 2^15 / 2^16: the fp64-size working limbs take the lift-fused one-kernel transforms (the fp64 lift reads source
-    // limbs of either size), the others go through the digit buffer and the u64 kernels
-    u32 fpmask = 0;
-    for (int j = 0; j < nw; j++)
-        if (c->limbs_host[A.w.idx[j]].Wd) fpmask |= 1u << j;
-    const u32 allmask = (1u << nw) - 1u;
-    const bool lift_mixed = !lift_fused && (c->logN == 15 || c->logN == 16) && c->variant == 0 && fpmask != 0 && fpmask != allmask &&
-                            (((uintptr_t)ct | (uintptr_t)dig) & 15u) == 0;
-    if (lift_fused) {
-        // digits: centred lift of limb i of c[end] into every working limb, fused into the forward NTT's loads
-        ntt_io_t io = io_plain();
-        io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys;
-        rc = run_ntt(c, false, ct, dig, batch * level * nw, A.w, &io);
-        if (rc) return rc;
-    } else if (lift_mixed) {
-        ntt_io_t io = io_plain();
-        io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys; io.limb_mask = fpmask;
-        rc = run_ntt_large(c, false, ct, dig, batch * level * nw, A.w, io, &io, true, true);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_ks_digits, row_grid((unsigned)(batch * level * nw), (size_t)c->N), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n, allmask & ~fpmask);
-        HIP_TRY(hipGetLastError());
-        ntt_io_t iw = io_plain();
-        iw.limb_mask = allmask & ~fpmask;
-        rc = run_ntt_large(c, false, dig, dig, batch * level * nw, A.w, iw, nullptr, false);
-        if (rc) return rc;
-    } else {
-        hipLaunchKernelGGL(k_ks_digits, row_grid((unsigned)(batch * level * nw), (size_t)c->N), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n, 0u);
-        HIP_TRY(hipGetLastError());
-        rc = run_ntt(c, false, dig, dig, batch * level * nw, A.w);
-        if (rc) return rc;
-    }
-    const unsigned gx = (n + 255) / 256;
-    // enough workgroups to fill the chip: split the batch into slices (the key is re-read once per slice)
-    const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx - 1) / (nw * gx)));
-    bool narrow = (n % 2 == 0);
-    for (int j = 0; j < nw; j++) narrow = narrow && (c->limbs_host[A.w.idx[j]].q >> 52) == 0;
-    if (narrow) {
-        const unsigned gx2 = (n / 2 + 255) / 256;
-        const unsigned bs2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx2 - 1) / (nw * gx2)));
-        hipLaunchKernelGGL(k_ks_inner_n2<8>, dim3((unsigned)nw * gx2 * bs2), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2);
-    } else {
-        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit);
-    }
-    HIP_TRY(hipGetLastError());
-    if (c->logN == 16 && c->variant == 0 && sel_fp(c, A.w, 2) && level >= 2 && (((uintptr_t)S | (uintptr_t)dig) & 15u) == 0) {
-        // N = 2^16: the paired sub-block inverse into the (now free) digit buffer, then the two inverse top stages together with
-        // the tail (k_ks_top_tail<2>) instead of k_ntt_inv_top<2> + k_ks_rescale_add / k_ks_add_ct
-        rc = launch_subpair<ArithFp>(c, true, S, dig, batch * 2 * nw, A.w, 2, 0u);
-        if (rc) return rc;
-        rescale_arg_t ra;
-        memset(&ra, 0, sizeof ra);
-        if (special) {
-            const u64 P = c->q[Lk - 1];
-            for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
-        }
-        hipLaunchKernelGGL(k_ks_top_tail<2>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 4), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
-        HIP_TRY(hipGetLastError());
-        return TFHE_OK;
-    }
-    if (special) {
-        rc = run_ntt(c, true, S, S, batch * 2 * nw, A.w);
-        if (rc) return rc;
-        rescale_arg_t ra;
-        memset(&ra, 0, sizeof ra);
-        const u64 P = c->q[Lk - 1];
-        for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
-        hipLaunchKernelGGL(k_ks_rescale_add, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, S, ct, out, c->limbs_dev, A, ra, n, add_s);
-        HIP_TRY(hipGetLastError());
-        return TFHE_OK;
-    }
-    if (c->logN <= 14) {  // out = c + INTT(S), the addition fused into the inverse NTT's stores
-        ntt_io_t io = io_plain();
-        io.mode = 2; io.gsz = (u32)(2 * level); io.src_gstride = io.gsz; io.dst_gstride = io.gsz;
-        io.add_rows = add_s * (u32)level; io.add_gstride = (u32)(polys * level); io.addend = ct;
-        return run_ntt(c, true, S, out, batch * 2 * nw, A.w, &io);
-    }
-    rc = run_ntt(c, true, S, out, batch * 2 * nw, A.w);
+    rc = ks_digits_fwd(c, A, ct, dig, batch);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ks_add_ct, row_grid((unsigned)(batch * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, ct, out, c->limbs_dev, A, n, add_s);
-    HIP_TRY(hipGetLastError());
-    return TFHE_OK;
+    return ks_finish(c, A, Lk, evk, ct, out, batch, S, dig, dig, 0);
 }
 
 static int ks_check(tfhe_ctx* c, int Lk, int level, int special, const void* evk, int n_digits, const void* ct, int polys, const void* out, int64_t batch) {
@@ -1007,6 +1053,91 @@ int tfhe_keyswitch(tfhe_ctx* c, int Lk, int level, int special, const uint64_t* 
     if (rc) return rc;
     return keyswitch_impl(c, Lk, level, special, evk, ct, polys, out, batch, 0, false);
 }
+// Hoisted rotations: rotate(gk_r, c) for r < n_rot from ONE digit decomposition.  The centred RNS digits commute with the
+// automorphism (a signed permutation of coefficients; the centred representative of -x is the negative of that of x, q odd),
+// and in the NTT domain the automorphism is the permutation galois_ntt_pos.  With the key rows permuted by g^-1 once per key
+// (tfhe_galois_key_prepare) the inner product runs coalesced on the transformed digits of the UNrotated ciphertext and yields
+// sigma_g^-1 of the sums; the automorphism is applied after the inverse transform, over 2 nw rows instead of level nw:
+// level * nw forward transforms once instead of per rotation.  Bit-identical to n_rot calls of tfhe_rotate.
+static u64 inv_mod_2n(u64 g, u64 twoN) {  // g odd, twoN a power of two: Newton iteration
+    u64 x = g;
+    for (int i = 0; i < 6; i++) x *= 2 - g * x;
+    return x & (twoN - 1);
+}
+// evk_out = the Galois key of x -> x^g with every NTT-domain row permuted by g^-1 (tfhe_rotate_many with prepared = 1)
+int tfhe_galois_key_prepare(tfhe_ctx* c, int Lk, int n_digits, uint64_t g, const uint64_t* evk, uint64_t* evk_out) {
+    if (!c || !evk || !evk_out || evk == evk_out) return fail(TFHE_E_BADARG, "null or aliased argument");
+    if (Lk < 1 || Lk > c->L || n_digits < 1) return fail(TFHE_E_LEVEL_MISMATCH, "key shape outside the ring");
+    if ((g & 1) == 0 || g >= 2 * (u64)c->N) return fail(TFHE_E_BADARG, "galois element must be odd and below 2N");
+    const u64 ginv = inv_mod_2n(g, 2 * (u64)c->N);
+    hipLaunchKernelGGL(k_ntt_perm, row_grid((unsigned)(n_digits * 2 * Lk), (size_t)c->N), dim3(256), 0, c->stream, evk, evk_out, ginv, (u32)c->N);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
+int tfhe_rotate_many(tfhe_ctx* c, int Lk, int level, int special, const uint64_t* const* evks, int n_digits, int prepared,
+                     const uint64_t* galois, int n_rot, const uint64_t* ct, uint64_t* out, int64_t batch) {
+    if (!evks || !galois || n_rot < 0) return fail(TFHE_E_BADARG, "null argument");
+    if (n_rot == 0) return TFHE_OK;
+    for (int r = 0; r < n_rot; r++) {
+        int rc = ks_check(c, Lk, level, special, evks[r], n_digits, ct, 2, out, batch);
+        if (rc) return rc;
+        if ((galois[r] & 1) == 0 || galois[r] >= 2 * (u64)c->N) return fail(TFHE_E_BADARG, "galois element must be odd and below 2N");
+    }
+    const int nw = special ? level + 1 : level, polys = 2;
+    const size_t N = (size_t)c->N;
+    if (!prepared && c->logN == 14 && ks_fused14(c, Lk, level, special)) {
+        // N = 2^14 on fp64-size moduli: the fused key switch (digits never leave the registers) beats the hoisted three-kernel
+        // path (measured 126 k against 110 k rotations/s at 6 limbs + special prime) -- same bits either way
+        for (int r = 0; r < n_rot; r++) {
+            int rc = keyswitch_impl(c, Lk, level, special, evks[r], ct, 2, out + (size_t)r * batch * 2 * level * N, batch, galois[r], true);
+            if (rc) return rc;
+        }
+        return TFHE_OK;
+    }
+    ks_arg_t A;
+    memset(&A, 0, sizeof A);
+    A.level = level; A.nw = nw; A.special = special; A.polys = polys;
+    A.w.n = nw;
+    for (int j = 0; j < level; j++) A.w.idx[j] = j;
+    if (special) A.w.idx[level] = Lk - 1;
+    // workspace per ciphertext: S (2 nw rows) + digits (level nw) + T (2 nw) + rotated input (2 level); + one prepared key
+    const size_t per_ct = ((size_t)4 * nw + (size_t)level * nw + (size_t)polys * level) * N * 8;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)((8192ull << 20) / per_ct)}));
+    const size_t ntt_tmp = c->logN > 14 ? (size_t)chunk * std::max(2, level) * nw * N * 8 : 0;
+    const size_t key_bytes = prepared ? 0 : (size_t)n_digits * 2 * Lk * N * 8;
+    void* ws = nullptr;
+    int rc = ensure_ws(c, ntt_tmp + chunk * per_ct + key_bytes, &ws);
+    if (rc) return rc;
+    u64* S = (u64*)((char*)ws + ntt_tmp);
+    u64* dig = S + (size_t)chunk * 2 * nw * N;
+    u64* T = dig + (size_t)chunk * level * nw * N;
+    u64* rot = T + (size_t)chunk * 2 * nw * N;
+    u64* keytmp = rot + (size_t)chunk * polys * level * N;
+    limb_sel_t sl;
+    sl.n = level;
+    for (int j = 0; j < level; j++) sl.idx[j] = j;
+    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int64_t nb = std::min(chunk, batch - b0);
+        const u64* cin = ct + (size_t)b0 * polys * level * N;
+        rc = ks_digits_fwd(c, A, cin, dig, nb);
+        if (rc) return rc;
+        for (int r = 0; r < n_rot; r++) {
+            const u64* key = evks[r];
+            if (!prepared) {
+                rc = tfhe_galois_key_prepare(c, Lk, n_digits, galois[r], evks[r], keytmp);
+                if (rc) return rc;
+                key = keytmp;
+            }
+            rc = do_galois(c, cin, rot, galois[r], nb * polys * level, sl);   // the addend sigma_g(c_1) (and sigma_g(c_2), unused)
+            if (rc) return rc;
+            rc = ks_finish(c, A, Lk, key, rot, out + ((size_t)r * batch + b0) * 2 * level * N, nb, S, dig, T, galois[r]);
+            if (rc) return rc;
+        }
+    }
+    return TFHE_OK;
+}
+
 int tfhe_rotate(tfhe_ctx* c, int Lk, int level, int special, const uint64_t* evk, int n_digits, uint64_t g, const uint64_t* ct, uint64_t* out, int64_t batch) {
     int rc = ks_check(c, Lk, level, special, evk, n_digits, ct, 2, out, batch);
     if (rc) return rc;

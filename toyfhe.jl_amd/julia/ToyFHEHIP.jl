@@ -270,6 +270,24 @@ function ToyFHE.rotate(gk::ToyFHE.GaloisKey, c::CipherText{Enc,P,<:RingElement{â
     CipherText{Enc}(c.params, unpack(out, â„›, 2))
 end
 
+# hoisted rotations: [rotate(gk, c) for gk in gks] from one digit decomposition of c (tfhe_rotate_many)
+function rotate_many(gks::Vector{<:ToyFHE.GaloisKey}, c::CipherText{Enc,P,<:RingElement{â„›,T,<:HipVector}}) where {Enc,P,â„›,T}
+    @assert length(c.cs) == 2
+    ek1 = gks[1].key; keyring = NTT.ring(ek1.key[1].mask); Lk = nlimbs(eltype(keyring)); level = nlimbs(T)
+    ct = pack(c); n = degree(â„›); out = HipVector{T}(2 * level * length(gks), n)
+    keys = Ptr{UInt64}[pack(gk.key).ptr for gk in gks]; gs = UInt64[gk.galois_element for gk in gks]
+    check(ccall((:tfhe_rotate_many, lib), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Ptr{UInt64}}, Cint, Cint, Ptr{UInt64}, Cint, Ptr{UInt64}, Ptr{UInt64}, Int64),
+                hipring(keyring).handle, Lk, level, ek1.params isa ModulusRaised ? 1 : 0, keys, length(ek1.key), 0, gs, length(gks),
+                ct.ptr, out.ptr, 1))
+    map(1:length(gks)) do r
+        part = HipVector{T}(2 * level, n)
+        check(ccall((:tfhe_memcpy_d2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                    hipring(â„›).handle, part.ptr, out.ptr + 8 * (r - 1) * 2 * level * n, 8 * 2 * level * n))
+        CipherText{Enc}(c.params, unpack(part, â„›, 2))
+    end
+end
+
 # ---- CKKS encode / decode (ckksencoding.jl:56-97) on the device --------------------------------------------------------
 # denom = mant * 2^exp2 with a 64-bit mant (exact for 2^k and for integers below 2^64 times 2^k; to 2^-63 otherwise)
 function scale_parts(denom)

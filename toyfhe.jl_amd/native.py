@@ -117,6 +117,8 @@ def lib():
         "tfhe_keyswitch": [vp, i32, i32, i32, vp, i32, vp, i32, vp, i64],
         "tfhe_rotate": [vp, i32, i32, i32, vp, i32, u64, vp, vp, i64],
         "tfhe_keyswitch_window": [vp, i32, i32, vp, i32, vp, i32, vp, i64],
+        "tfhe_rotate_many": [vp, i32, i32, i32, C.POINTER(vp), i32, i32, u64p, i32, vp, vp, i64],
+        "tfhe_galois_key_prepare": [vp, i32, i32, u64, vp, vp],
         "tfhe_sample_uniform": [vp, i32, u64, C.c_uint32, u64, vp, i64],
         "tfhe_sample_gaussian": [vp, i32, C.c_double, u64, u64, C.c_uint32, u64, vp, i64],
         "tfhe_ckks_encode": [vp, i32, u64, i32, vp, vp, i64],
@@ -149,7 +151,7 @@ EXPORTED_SYMBOLS = [
     "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
     "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_pack_poly", "tfhe_unpack_poly", "tfhe_broadcast_poly", "tfhe_alloc_stats", "tfhe_alloc_trim", "tfhe_comm_id", "tfhe_comm_create", "tfhe_comm_destroy", "tfhe_gather", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
     "tfhe_mul", "tfhe_mad", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
-    "tfhe_keyswitch", "tfhe_rotate", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
+    "tfhe_keyswitch", "tfhe_rotate", "tfhe_rotate_many", "tfhe_galois_key_prepare", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
     "tfhe_bfv_plan_set_variant", "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
     "tfhe_event_create", "tfhe_event_destroy", "tfhe_event_record", "tfhe_event_elapsed_ms",
 ]
@@ -319,6 +321,15 @@ class Context:
 
     def rotate(self, key_limbs, level, special, evk, n_digits, g, ct, out, batch):
         check(lib().tfhe_rotate(self.h, key_limbs, level, int(bool(special)), evk, n_digits, int(g), ct, out, batch))
+
+    def rotate_many(self, key_limbs, level, special, evks, n_digits, gs, ct, out, batch, prepared=False):
+        ptrs = (C.c_void_p * len(evks))(*[int(p) for p in evks])
+        garr = (C.c_uint64 * len(gs))(*[int(g) for g in gs])
+        check(lib().tfhe_rotate_many(self.h, key_limbs, level, int(bool(special)), ptrs, n_digits, int(bool(prepared)), garr, len(evks),
+                                     ct, out, batch))
+
+    def galois_key_prepare(self, key_limbs, n_digits, g, evk, evk_out):
+        check(lib().tfhe_galois_key_prepare(self.h, key_limbs, n_digits, int(g), evk, evk_out))
 
     def prof_enable(self, on=True):
         check(lib().tfhe_prof_enable(self.h, int(on)))

@@ -288,6 +288,18 @@ class EvalMultKey:
 class GaloisKey:
     def __init__(self, galois_element: int, key: KeySwitchKey):
         self.galois_element, self.key = galois_element, key
+        self._prepared = None
+
+    def prepared(self) -> DeviceBuffer:
+        """the packed key with its NTT-domain rows permuted by g^-1 (tfhe_galois_key_prepare), once per key: what the hoisted
+        rotations consume"""
+        if self._prepared is None:
+            ring = self.key.key[0].mask.ring
+            src = self.key.packed()
+            dst = DeviceBuffer(src.n)
+            ring.ctx.galois_key_prepare(ring.L, len(self.key.key), self.galois_element, src.ptr, dst.ptr)
+            self._prepared = dst
+        return self._prepared
 
 
 class CipherText:
@@ -621,6 +633,45 @@ def rotate(gk: GaloisKey, c: CipherText) -> CipherText:
     if len(c) != 2:
         raise AssertionError("rotate takes a 2-element ciphertext")
     return keyswitch(gk.key, c, _galois=gk.galois_element)
+
+
+def rotate_many(gks, c: CipherText):
+    """[rotate(gk, c) for gk in gks] from one digit decomposition of c (tfhe_rotate_many: the forward transforms of the RNS
+    digits are shared by all rotations); each result is bit-identical to `rotate(gk, c)`.  RNS-digit keys (relin_window = 0)."""
+    gks = list(gks)
+    if len(c) != 2:
+        raise AssertionError("rotate takes a 2-element ciphertext")
+    if not gks:
+        return []
+    params = gks[0].key.params
+    if any(g.key.params is not params for g in gks) or params.relin_window != 0:
+        raise UsageError("hoisted rotations need Galois keys of one parameter set with RNS digits")
+    keyring = gks[0].key.key[0].mask.ring
+    ring, n, batch = c[0].ring, c[0].count, c[0].batch
+    level, special = ring.L, isinstance(params, ModulusRaised)
+    if keyring.idx != list(range(keyring.L)) or ring.idx != list(range(level)):
+        raise UsageError("ciphertext ring is not a prefix of the key ring")
+    if ring.ctx is not keyring.ctx:
+        if ring.N != keyring.N or ring.moduli != keyring.moduli[:level] or ring.psi != keyring.psi[:level]:
+            raise UsageError("ciphertext and key belong to different rings")
+        ring.ctx.sync()
+    sz = level * ring.N
+    ct = _pack([x.coeffs_primal() for x in c.cs], ring, n, ctx=keyring.ctx)
+    out = DeviceBuffer(len(gks) * n * 2 * sz)
+    keyring.ctx.rotate_many(keyring.L, level, special, [g.prepared().ptr for g in gks], len(gks[0].key.key),
+                            [g.galois_element for g in gks], ct.ptr, out.ptr, n, prepared=True)
+    res = []
+    for r in range(len(gks)):
+        view = _View(out, r * n * 2 * sz)
+        res.append(CipherText(c.params, _unpack(view, ring, n, 2, batch, primal=True, ctx=keyring.ctx), c.scale))
+    return res
+
+
+class _View:
+    """a window into a DeviceBuffer (keeps the parent alive)"""
+
+    def __init__(self, parent, word_offset):
+        self.parent, self.ptr = parent, parent.ptr + word_offset * 8
 
 
 def modswitch(c: CipherText) -> CipherText:
