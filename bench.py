@@ -211,7 +211,7 @@ def main():
             gui, dur = per_ct("GRBM_GUI_ACTIVE"), per_ct("duration_ns")
             if gui and dur:
                 clock_ghz = gui / 8 / dur                             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; shader clock of the profiled pass
-                valu_frac_clk = valu_gips / (N_SIMD * clock_ghz / 4)
+                valu_frac_clk = per_ct("SQ_INSTS_VALU") * 4.0 / (N_SIMD * gui / 8)   # counters only: issue slots used / available in that pass
             for k in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
                       "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_LDS"):
                 if all(k in v for v in fused.values()):
@@ -225,7 +225,7 @@ def main():
         "peak": VALU_PEAK_GIPS if valu_frac is not None else HBM_PEAK_GBS,
         "unit": "G wave64-VALU-instr/s (1024 SIMDs x 2.4 GHz / 4 clk)" if valu_frac is not None else "GB/s",
         "frac": valu_frac if valu_frac is not None else teq / HBM_PEAK_GBS,
-        "frac_at_profiled_clock": valu_frac_clk, "profiled_clock_GHz": clock_ghz,
+        "valu_issue_util_profiled_pass": valu_frac_clk, "profiled_clock_GHz": clock_ghz,
         "hbm_frac": hbm_frac,
         "traffic": traffic,
         "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the two kernels, profiles/pmc_bench_kernels.json, "

@@ -237,6 +237,8 @@ class RingElement:
         """one ring element against a batch (the scalar-broadcast patterns of rlwe_she.jl:143, ckksencoding.jl:99-124):
         the present domain(s) repeated `batch` times on the device."""
         assert self.batch is None
+        if batch == 1:                                   # a batch of one shares the element's buffers
+            return RingElement(self.ring, self.primal, self.dual, 1)
         words = self.ring.L * self.ring.N
         def rep(b):
             if b is None:
