@@ -1076,9 +1076,10 @@ struct ks_arg_t {
 template <int DCH>
 __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, const u64* __restrict__ dig,
                                                    u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
-                                                   int Lk, u32 n, u32 batch, u32 bsplit) {
+                                                   int Lk, u32 n, u32 batch, u32 bsplit, u32 limb_mask) {
     // blockIdx.x = (slice * nw + j) * gx + tile; slice = which part of the batch this workgroup owns
     const u32 gx = (n + 255) / 256, tile = blockIdx.x % gx, j = (blockIdx.x / gx) % (u32)A.nw, slice = blockIdx.x / (gx * (u32)A.nw);
+    if (limb_mask && !((limb_mask >> j) & 1u)) return;  // rings of mixed modulus sizes: the narrow kernel takes the other limbs
     const u32 k = tile * 256 + threadIdx.x;
     const u32 per = (batch + bsplit - 1) / bsplit, b_lo = slice * per, b_hi = b_lo + per < batch ? b_lo + per : batch;
     if (k >= n) return;
@@ -1126,9 +1127,10 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
 template <int DCH>
 __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk, const u64* __restrict__ dig,
                                                       u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
-                                                      int Lk, u32 n, u32 batch, u32 bsplit) {
+                                                      int Lk, u32 n, u32 batch, u32 bsplit, u32 limb_mask) {
     static_assert(DCH + 1 <= 16, "acc52 term budget");
     const u32 gx = (n / 2 + 255) / 256, tile = blockIdx.x % gx, j = (blockIdx.x / gx) % (u32)A.nw, slice = blockIdx.x / (gx * (u32)A.nw);
+    if (limb_mask && !((limb_mask >> j) & 1u)) return;
     const u32 k = (tile * 256 + threadIdx.x) * 2;
     const u32 per = (batch + bsplit - 1) / bsplit, b_lo = slice * per, b_hi = b_lo + per < batch ? b_lo + per : batch;
     if (k >= n) return;

@@ -66,7 +66,7 @@ constexpr u32 lds_words() {
     return (LOGB - LOGT == 5) ? (m + 2u * (m >> 6) + (m >> 10) + 1) : (m + 4u * (m >> 6) + (m >> 9) + 1);
 }
 // elements per thread and pass partition (K stages per pass, at most log2(E))
-constexpr int logt_for(int logb) { return logb >= 14 ? logb - 5 : logb - 4; }
+constexpr int logt_for(int logb) { return logb >= 13 ? logb - 5 : logb - 4; }
 constexpr int pass_k_fwd(int logb, int logt, int s0) { return (logb - s0) >= (logb - logt) ? (logb - logt) : (logb - s0); }
 constexpr int pass_k_inv(int logb, int logt, int s_end) { return (s_end % (logb - logt)) ? (s_end % (logb - logt)) : (logb - logt); }
 

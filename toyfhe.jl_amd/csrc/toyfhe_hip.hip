@@ -850,14 +850,20 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
     const unsigned gx = (n + 255) / 256;
     // enough workgroups to fill the chip: split the batch into slices (the key is re-read once per slice)
     const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx - 1) / (nw * gx)));
-    bool narrow = (n % 2 == 0);
-    for (int j = 0; j < nw; j++) narrow = narrow && (c->limbs_host[A.w.idx[j]].q >> 52) == 0;
-    if (narrow) {
+    u32 nmask = 0;  // working limbs below 2^52: the two-coefficient, carry-free kernel; the others: the generic one
+    for (int j = 0; j < nw; j++)
+        if ((c->limbs_host[A.w.idx[j]].q >> 52) == 0) nmask |= 1u << j;
+    const u32 amask = (1u << nw) - 1u;
+    if (n % 2 != 0) nmask = 0;
+    if (nmask) {
         const unsigned gx2 = (n / 2 + 255) / 256;
         const unsigned bs2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx2 - 1) / (nw * gx2)));
-        hipLaunchKernelGGL(k_ks_inner_n2<8>, dim3((unsigned)nw * gx2 * bs2), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2);
-    } else {
-        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit);
+        hipLaunchKernelGGL(k_ks_inner_n2<8>, dim3((unsigned)nw * gx2 * bs2), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2,
+                           nmask == amask ? 0u : nmask);
+    }
+    if (nmask != amask) {
+        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit,
+                           nmask ? (amask & ~nmask) : 0u);
     }
     HIP_TRY(hipGetLastError());
     if (g != 0) {  // hoisted rotation: INTT, automorphism, tail
@@ -1224,7 +1230,7 @@ int tfhe_keyswitch_window(tfhe_ctx* c, int level, int window_bits, const uint64_
         rc = run_ntt(c, false, dig, dig, nb * n_windows * level, A.w);
         if (rc) return rc;
         const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nb, (4096 + level * gx - 1) / (level * gx)));
-        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)level * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, level, n, (u32)nb, bsplit);
+        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)level * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, level, n, (u32)nb, bsplit, 0u);
         HIP_TRY(hipGetLastError());
         if (c->logN <= 14) {
             ntt_io_t io = io_plain();
