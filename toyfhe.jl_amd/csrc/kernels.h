@@ -719,22 +719,49 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
         u64* d = dst + pl * ntot + brev_bits(ph, x);
         u64 w[2][E];  // the two sub-blocks' first-pass operands (element bits)
         {
+            // Load phase.  The LDS holds no row image while an item's operands are being formed, so the four quarters of the
+            // source row stream HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs) in 16 chunks of 32 KiB (two of the 32
+            // register positions x four quarters), NB = 4 chunk buffers, three chunks in flight while the top-stage arithmetic of
+            // the current one runs -- instead of four rounds of (32 register loads, wait, arithmetic).  One barrier per chunk:
+            // it publishes the chunk every wave helped to copy and, since each wave reads chunk c-1 before it arrives, frees that
+            // chunk's buffer for chunk c+3.
             const u32 tid = fresh_tid();
             const typename A::tw w1 = A::ld_fwd(C, 1u), w2 = A::ld_fwd(C, 2u), w3 = A::ld_fwd(C, 3u);
             const double sgn = ph ? -1.0 : 1.0;
-            constexpr int QC = 4;  // pieces of the load phase
+            constexpr int EC = 2, NCH = E / EC, NB = 4, AHEAD = 3;      // positions per chunk, chunks, buffers, chunks in flight
+            constexpr int CH_WORDS = 4 * EC << LOGT;                    // u64 per chunk: 4 quarters x EC x 2^LOGT
+            constexpr int PIECES = CH_WORDS * 8 / 1024, PER_WAVE = PIECES >> (LOGT - 6);
+            static_assert(PER_WAVE >= 1 && NB * CH_WORDS * 8 <= (int)(lds_words<LOGB, LOGT>() * 8), "chunk buffers fit the row image");
+            const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
+            const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) u64*)lds;
+            auto issue = [&](int c) {  // this wave's pieces of chunk c: piece p = quarter k, 128 words at pp
 #pragma unroll
-            for (int h = 0; h < QC; h++) {  // in pieces: bounds the raw operands in flight next to the 128 result registers
-                u64 q[4][E / QC];
-#pragma unroll
-                for (int r = 0; r < E / QC; r++) {
-                    const u32 j = tid + ((u32)(h * (E / QC) + r) << LOGT);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) q[k][r] = s[j + ((u32)k << LOGB)];
+                for (int i = 0; i < PER_WAVE; i++) {
+                    const u32 p = wave * PER_WAVE + (u32)i, k = p / (PIECES / 4), pp = p % (PIECES / 4);
+                    const u64* g = s + ((size_t)k << LOGB) + (size_t)c * (EC << LOGT) + pp * 128u + lane * 2u;
+                    glds16(g, lds0 + (((u32)(c % NB) * CH_WORDS + k * (EC << LOGT) + pp * 128u) << 3));
                 }
-                TFHE_SCHED_FENCE();
+            };
+            if (!first) __syncthreads();  // the previous item's last pass has read its LDS image
 #pragma unroll
-                for (int r = 0; r < E / QC; r++) {
+            for (int c = 0; c < AHEAD; c++) issue(c);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int later = (NCH - 1 - c) < (AHEAD - 1) ? (NCH - 1 - c) : (AHEAD - 1);   // chunks issued after c and still in flight
+                if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (c + AHEAD < NCH) issue(c + AHEAD);
+                u64 q[4][EC];
+                const u64* buf = lds + (size_t)(c % NB) * CH_WORDS;
+#pragma unroll
+                for (int r = 0; r < EC; r++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) q[k][r] = buf[k * (EC << LOGT) + (r << LOGT) + tid];
+#pragma unroll
+                for (int r = 0; r < EC; r++) {
                     double xin[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) xin[k] = LIFT ? A::from_global_lift(q[k][r], C, lf, true) : fp_from_u64(q[k][r]);
@@ -743,19 +770,18 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
                     const double t3 = fp_mulmod_c(xin[3], w1, C.p, C.pinv);
                     // |y| <= 1.88 p, products <= 1.21 p (fp64arith.h); the sub-blocks take reduced operands
                     const double u0 = fp_mulmod_c(x1 + t3, w2, C.p, C.pinv), u1 = fp_mulmod_c(x1 - t3, w3, C.p, C.pinv);
-                    w[0][h * (E / QC) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u0, x0 + t2), C.p, C.pinv));
-                    w[1][h * (E / QC) + r] = A::to_lds(fp_reduce(fp_fma(sgn, u1, x0 - t2), C.p, C.pinv));
+                    w[0][c * EC + r] = A::to_lds(fp_reduce(fp_fma(sgn, u0, x0 + t2), C.p, C.pinv));
+                    w[1][c * EC + r] = A::to_lds(fp_reduce(fp_fma(sgn, u1, x0 - t2), C.p, C.pinv));
                 }
-                TFHE_SCHED_FENCE();
             }
+            first = false;
         }
         u64 held[E];
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const u32 sb = ph + ((u32)half << (x - 1)), pre = (1u << x) + sb;
             const u32 tid = fresh_tid();
-            if (!first) __syncthreads();  // the previous transform's last pass has read LDS
-            first = false;
+            __syncthreads();  // every wave has read the last chunk / the previous transform's last pass has read LDS
             {
                 typename A::elem v[E];
                 fwd_compute<A, LOGB, LOGT, 0, K1, false, false, 0>(v, w[half], nullptr, C, tid, pre);
