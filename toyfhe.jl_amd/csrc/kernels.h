@@ -338,6 +338,61 @@ __device__ __forceinline__ void glds16(const void* gsrc, u32 lds_byte) {  // one
                  : "v"(gsrc), "s"(lds_byte)
                  : "memory");
 }
+// Streaming load phase of the kernels that form a sub-block's first-pass operands from NSRC strided parts of a source row
+// (the 2^15 / 2^16 transforms: halves / quarters at distance 2^LOGB words).  While those operands are being formed the LDS
+// holds no row image, so the parts stream HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs) and are read back from
+// there, a few KiB per wave in flight while the arithmetic of the current step runs -- instead of a few rounds of (register
+// loads, wait, arithmetic) with every round's latency exposed.  WAVE-PRIVATE: a wave copies exactly the words its own lanes
+// will read (register position e of lane l is row word wave*64 + l + (e << LOGT) of each part: 512 contiguous bytes per wave,
+// so one 1-KiB DMA instruction carries two such segments, lanes 0-31 one and lanes 32-63 the other), into its own ring of
+// RING steps -- no barrier inside the phase, only vmcnt waits (the counter is in order: waiting for all but the youngest
+// k instructions).  consume(e, q) receives the NSRC words of register position e.  The caller puts a barrier between the
+// previous LDS readers and this call, and one before the next LDS writer.
+template <int LOGB, int LOGT, int NSRC, int EC, class F>
+__device__ __forceinline__ void dma_stream_load(u64* lds, const u64* s, u32 tid, F&& consume) {
+    constexpr int E = 1 << (LOGB - LOGT), NSTEP = E / EC, RING = 4, AHEAD = RING - 1;
+    constexpr int IPS = EC * NSRC / 2;                                    // DMA instructions per step (two segments each)
+    constexpr int WAVES = 1 << (LOGT - 6);
+    static_assert((EC * NSRC) % 2 == 0 && NSTEP >= AHEAD, "step geometry");
+    static_assert(WAVES * RING * IPS * 128 <= (int)lds_words<LOGB, LOGT>(), "the rings fit the row image");
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u, hl = lane >> 5, l32 = lane & 31u;
+    const u32 ring_w = wave * (RING * IPS * 128u);                        // this wave's ring, in words
+    const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) u64*)lds + (ring_w << 3);
+    const u64* sw = s + wave * 64u + l32 * 2u;
+    auto issue = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < IPS; i++) {
+            const u32 sg = 2u * (u32)i + hl, r = sg / NSRC, k = sg % NSRC;   // lanes 0-31: segment 2i, lanes 32-63: segment 2i+1
+            const u64* g = sw + ((size_t)k << LOGB) + ((size_t)(c * EC + (int)r) << LOGT);
+            glds16(g, lds0 + ((u32)((c % RING) * IPS + i) << 10));
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < AHEAD; c++) issue(c);
+#pragma unroll
+    for (int c = 0; c < NSTEP; c++) {
+        const int later = (NSTEP - 1 - c) < (AHEAD - 1) ? (NSTEP - 1 - c) : (AHEAD - 1);   // steps issued after c and still in flight
+        if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPS) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        u64 q[EC][NSRC];
+        const u64* buf = lds + ring_w + (size_t)(c % RING) * IPS * 128 + lane;
+#pragma unroll
+        for (int r = 0; r < EC; r++)
+#pragma unroll
+            for (int k = 0; k < NSRC; k++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int sg = r * NSRC + k;
+                q[r][k] = buf[(sg >> 1) * 128 + (sg & 1) * 64];
+            }
+        if (c + AHEAD < NSTEP) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the slot of step c-1 ... c is read before it is refilled
+            issue(c + AHEAD);
+        }
+#pragma unroll
+        for (int r = 0; r < EC; r++) consume(c * EC + r, q[r]);
+    }
+}
 // LDS-DMA of one 2^LOGB-word row into the lane-linear LDS image, PER_WAVE 1-KiB pieces per wave; as a progress hook
 // it issues piece k once the butterfly count passes k/PER_WAVE of the pass
 template <int LOGB, int LOGT>
@@ -517,6 +572,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
         u64* d = dst + ((size_t)item << (LOGB + 1));
         u64 wa[E], wb[E];  // the two sub-blocks' first-pass operands (element bits)
         {
+            // (dma_stream_load, which pays in k_ntt_fwd_quad with its four rounds of loads, measured 10 % SLOWER here -- 2.2
+            // against 2.45 TB/s: two rounds of register loads keep nearly the whole row in flight already)
             const typename A::tw w1 = A::ld_fwd(C, 1u);
 #pragma unroll
             for (int h = 0; h < 2; h++) {  // two halves: bounds the raw operands in flight next to the 128 result registers
@@ -719,61 +776,23 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
         u64* d = dst + pl * ntot + brev_bits(ph, x);
         u64 w[2][E];  // the two sub-blocks' first-pass operands (element bits)
         {
-            // Load phase.  The LDS holds no row image while an item's operands are being formed, so the four quarters of the
-            // source row stream HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs) in 16 chunks of 32 KiB (two of the 32
-            // register positions x four quarters), NB = 4 chunk buffers, three chunks in flight while the top-stage arithmetic of
-            // the current one runs -- instead of four rounds of (32 register loads, wait, arithmetic).  One barrier per chunk:
-            // it publishes the chunk every wave helped to copy and, since each wave reads chunk c-1 before it arrives, frees that
-            // chunk's buffer for chunk c+3.
+            // load phase: the four quarters stream through the LDS (dma_stream_load), top-stage arithmetic per chunk
             const u32 tid = fresh_tid();
             const typename A::tw w1 = A::ld_fwd(C, 1u), w2 = A::ld_fwd(C, 2u), w3 = A::ld_fwd(C, 3u);
             const double sgn = ph ? -1.0 : 1.0;
-            constexpr int EC = 2, NCH = E / EC, NB = 4, AHEAD = 3;      // positions per chunk, chunks, buffers, chunks in flight
-            constexpr int CH_WORDS = 4 * EC << LOGT;                    // u64 per chunk: 4 quarters x EC x 2^LOGT
-            constexpr int PIECES = CH_WORDS * 8 / 1024, PER_WAVE = PIECES >> (LOGT - 6);
-            static_assert(PER_WAVE >= 1 && NB * CH_WORDS * 8 <= (int)(lds_words<LOGB, LOGT>() * 8), "chunk buffers fit the row image");
-            const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
-            const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) u64*)lds;
-            auto issue = [&](int c) {  // this wave's pieces of chunk c: piece p = quarter k, 128 words at pp
-#pragma unroll
-                for (int i = 0; i < PER_WAVE; i++) {
-                    const u32 p = wave * PER_WAVE + (u32)i, k = p / (PIECES / 4), pp = p % (PIECES / 4);
-                    const u64* g = s + ((size_t)k << LOGB) + (size_t)c * (EC << LOGT) + pp * 128u + lane * 2u;
-                    glds16(g, lds0 + (((u32)(c % NB) * CH_WORDS + k * (EC << LOGT) + pp * 128u) << 3));
-                }
-            };
             if (!first) __syncthreads();  // the previous item's last pass has read its LDS image
+            dma_stream_load<LOGB, LOGT, 4, 2>(lds, s, tid, [&](int e, const u64* q) {
+                double xin[4];
 #pragma unroll
-            for (int c = 0; c < AHEAD; c++) issue(c);
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                constexpr int dummy = 0; (void)dummy;
-                const int later = (NCH - 1 - c) < (AHEAD - 1) ? (NCH - 1 - c) : (AHEAD - 1);   // chunks issued after c and still in flight
-                if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
-                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (c + AHEAD < NCH) issue(c + AHEAD);
-                u64 q[4][EC];
-                const u64* buf = lds + (size_t)(c % NB) * CH_WORDS;
-#pragma unroll
-                for (int r = 0; r < EC; r++)
-#pragma unroll
-                    for (int k = 0; k < 4; k++) q[k][r] = buf[k * (EC << LOGT) + (r << LOGT) + tid];
-#pragma unroll
-                for (int r = 0; r < EC; r++) {
-                    double xin[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) xin[k] = LIFT ? A::from_global_lift(q[k][r], C, lf, true) : fp_from_u64(q[k][r]);
-                    const double x0 = xin[0], x1 = xin[1];
-                    const double t2 = fp_mulmod_c(xin[2], w1, C.p, C.pinv);
-                    const double t3 = fp_mulmod_c(xin[3], w1, C.p, C.pinv);
-                    // |y| <= 1.88 p, products <= 1.21 p (fp64arith.h); the sub-blocks take reduced operands
-                    const double u0 = fp_mulmod_c(x1 + t3, w2, C.p, C.pinv), u1 = fp_mulmod_c(x1 - t3, w3, C.p, C.pinv);
-                    w[0][c * EC + r] = A::to_lds(fp_reduce(fp_fma(sgn, u0, x0 + t2), C.p, C.pinv));
-                    w[1][c * EC + r] = A::to_lds(fp_reduce(fp_fma(sgn, u1, x0 - t2), C.p, C.pinv));
-                }
-            }
+                for (int k = 0; k < 4; k++) xin[k] = LIFT ? A::from_global_lift(q[k], C, lf, true) : fp_from_u64(q[k]);
+                const double x0 = xin[0], x1 = xin[1];
+                const double t2 = fp_mulmod_c(xin[2], w1, C.p, C.pinv);
+                const double t3 = fp_mulmod_c(xin[3], w1, C.p, C.pinv);
+                // |y| <= 1.88 p, products <= 1.21 p (fp64arith.h); the sub-blocks take reduced operands
+                const double u0 = fp_mulmod_c(x1 + t3, w2, C.p, C.pinv), u1 = fp_mulmod_c(x1 - t3, w3, C.p, C.pinv);
+                w[0][e] = A::to_lds(fp_reduce(fp_fma(sgn, u0, x0 + t2), C.p, C.pinv));
+                w[1][e] = A::to_lds(fp_reduce(fp_fma(sgn, u1, x0 - t2), C.p, C.pinv));
+            });
             first = false;
         }
         u64 held[E];
@@ -1421,6 +1440,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
             typename A::elem v[E];
             {
                 u64 op[E];  // first-pass operands of this sub-block (element bits)
+                // (the LDS-DMA streaming of dma_stream_load, which pays in k_ntt_fwd_quad, measured 7-9 % SLOWER here: cfg#3
+                // 32.6 k against 35.1 k key switches/s -- the piece-wise register loads below stay)
                 constexpr int PC = 4 * X, PE = E / PC;  // pieces of the load phase (bounds the raw words in flight)
 #pragma unroll
                 for (int h = 0; h < PC; h++) {
