@@ -129,6 +129,7 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_block(con
             const ntt_limb_t& Li = LT[sel.idx[i]];
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
+            lift_wide_consts<A>(lf);
             lift = &lf;
         }
         if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_lift(cons
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qj = Lj.q;
             lf.bj = Lj.br;
+            lift_wide_consts<A>(lf);
             const typename A::ctx C = A::make(Lj);
             u64* gdst = dst + ((size_t)(item * io.nw + j) << LOGB);
             if (!first) __syncthreads();  // the previous transform's last pass has read LDS
@@ -565,6 +567,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
             const ntt_limb_t& Li = LT[sel.idx[i]];
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
+            lift_wide_consts<A>(lf);
         }
         if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
@@ -769,6 +772,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
             const ntt_limb_t& Li = LT[sel.idx[i]];
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
+            lift_wide_consts<A>(lf);
         }
         if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
         const typename A::ctx C = A::make(LT[sel.idx[j]]);

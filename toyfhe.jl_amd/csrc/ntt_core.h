@@ -120,6 +120,7 @@ struct no_hook {
 struct lift_t {
     u64 qi, half, qj;
     barrett_t bj;
+    double c32, qim;  // 2^32 mod q_j and q_i mod q_j (ArithFpWide: lifts out of source limbs above 2^52; see lift_wide_consts)
 };
 TFHE_HD u64 lift_digit(u64 x, const lift_t& f) {
     return x > f.half ? negmod(barrett_reduce128(f.qi - x, 0, f.bj), f.qj) : barrett_reduce128(x, 0, f.bj);
@@ -257,14 +258,26 @@ struct ArithFp {
 // source limb per row).  A separate policy type, so that the kernels of uniform fp64 rings keep their branch-free first
 // pass (a run-time branch next to a load phase costs them a third of their rate).
 struct ArithFpWide : ArithFp {
-    static TFHE_HD elem from_global_lift(u64 x, const ctx& c, const lift_t& f, bool loose = false) {
-        if (f.qi >> 52) {
-            const double r = fp_from_u64(lift_digit(x, f));
-            return r + r > c.p ? r - c.p : r;
-        }
-        return ArithFp::from_global_lift(x, c, f, loose);
+    // branch-free, any source width below 2^62:  x = xh 2^32 + xl, both halves exact doubles (v_cvt_f64_u32);
+    //   centred digit = x - [x > q_i/2] q_i  =  xh (2^32 mod p) + xl - [x > q_i/2] (q_i mod p)   (mod p)
+    // one exact modular product, two exact sums (|.| < 1.5 p + 2^32 < 2^53), one reduction to |.| <= p/2.
+    static TFHE_HD elem from_global_lift(u64 x, const ctx& c, const lift_t& f, bool = false) {
+        const double dl = (double)(u32)x, dh = (double)(u32)(x >> 32);
+        double r = fp_mulmod_c(dh, ftw_t{f.c32}, c.p, c.pinv) + dl;
+        r = x > f.half ? r - f.qim : r;
+        return fp_reduce(r, c.p, c.pinv);
     }
 };
+// the two per-(i, j) constants of ArithFpWide's lift; a no-op for the other policies
+template <class A>
+TFHE_HD void lift_wide_consts(lift_t& f) {
+    (void)f;
+}
+template <>
+TFHE_HD void lift_wide_consts<ArithFpWide>(lift_t& f) {
+    f.c32 = (double)barrett_reduce128(1ull << 32, 0, f.bj);
+    f.qim = (double)barrett_reduce128(f.qi, 0, f.bj);
+}
 
 // Optional transforms fused into the block kernels' global I/O (key switching, src/rlwe_she.jl:326-344):
 //   lift_t  : forward first pass reads limb i of a polynomial and lifts it, centred, into limb j --
