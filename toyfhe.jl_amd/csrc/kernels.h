@@ -912,6 +912,40 @@ __global__ __launch_bounds__(256) void k_ntt_fwd_top(const u64* __restrict__ src
     const u64 col = (u64)(blockIdx.x % chunks) * blockDim.x + threadIdx.x;
     if (col < stride) ntt_fwd_top<X>(src + ((size_t)row << logn), dst + ((size_t)row << logn), L.W, L.q, col, stride);
 }
+// the same top stages with the key switch's digit lift fused into the loads (ntt_io_t mode 1: row (b, i, j) reads limb i of
+// c[end] of ciphertext b and lifts it, centred, into working limb j): the u64 working limbs of rings that mix modulus sizes at
+// N > 2^14 -- the digit rows are never stored untransformed
+template <int X>
+__global__ __launch_bounds__(256) void k_ntt_fwd_top_lift(const u64* __restrict__ ct, u64* __restrict__ dst,
+                                                           const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int logn, ntt_io_t io) {
+    constexpr int R = 1 << X;
+    const u64 stride = (u64)1 << (logn - X);
+    const u32 chunks = (u32)((stride + 255) / 256);
+    const u32 row = blockIdx.x / chunks, j = row % io.nw, i = (row / io.nw) % io.level, b = row / (io.nw * io.level);
+    if (io.limb_mask && !((io.limb_mask >> j) & 1u)) return;
+    const ntt_limb_t L = LT[sel.idx[j]];
+    lift_t lf;
+    lf.qi = LT[sel.idx[i]].q; lf.half = lf.qi >> 1; lf.qj = L.q; lf.bj = L.br;
+    const u64 col = (u64)(blockIdx.x % chunks) * blockDim.x + threadIdx.x;
+    if (col >= stride) return;
+    const u64* s = ct + ((size_t)((b * io.polys + io.polys - 1) * io.level + i) << logn);
+    u64* d = dst + ((size_t)row << logn);
+    u64 v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = lift_digit(s[col + (u64)r * stride], lf);
+#pragma unroll
+    for (int dd = 0; dd < X; dd++) {
+        const int half = 1 << (X - 1 - dd);
+#pragma unroll
+        for (int g = 0; g < (1 << dd); g++) {
+            const tw_t w = ld_tw(L.W, (1u << dd) + (u32)g);
+#pragma unroll
+            for (int k = 0; k < half; k++) bfly_fwd(v[(g << (X - dd)) + k], v[(g << (X - dd)) + k + half], w, L.q);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) d[col + (u64)r * stride] = csub(csub(v[r], 2 * L.q), L.q);
+}
 template <int X>
 __global__ __launch_bounds__(256) void k_ntt_inv_top(const u64* __restrict__ src, u64* __restrict__ dst,
                                                       const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int logn, u32 limb_mask) {

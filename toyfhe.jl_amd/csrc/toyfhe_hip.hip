@@ -818,11 +818,21 @@ static int ks_digits_fwd(tfhe_ctx* c, const ks_arg_t& A, const u64* ct, u64* dig
         io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys; io.limb_mask = fpmask;
         rc = run_ntt_large(c, false, ct, dig, batch * level * nw, A.w, io, &io, true, true);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_ks_digits, row_grid((unsigned)(batch * level * nw), (size_t)c->N), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n, allmask & ~fpmask);
-        HIP_TRY(hipGetLastError());
-        ntt_io_t iw = io_plain();
+        // the larger working limbs: lift fused into the top-stage kernel (into the transform scratch), then the u64 block kernels
+        const int64_t rows = batch * level * nw;
+        const int x = c->logN - 14;
+        void* tmp = nullptr;
+        rc = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
+        if (rc) return rc;
+        ntt_io_t iw = io;
         iw.limb_mask = allmask & ~fpmask;
-        rc = run_ntt_large(c, false, dig, dig, batch * level * nw, A.w, iw, nullptr, false);
+        const dim3 tg((unsigned)((((c->N >> x) + 255) / 256) * rows));
+        if (x == 1) hipLaunchKernelGGL(k_ntt_fwd_top_lift<1>, tg, dim3(256), 0, c->stream, ct, (u64*)tmp, c->limbs_dev, A.w, c->logN, iw);
+        else hipLaunchKernelGGL(k_ntt_fwd_top_lift<2>, tg, dim3(256), 0, c->stream, ct, (u64*)tmp, c->limbs_dev, A.w, c->logN, iw);
+        HIP_TRY(hipGetLastError());
+        ntt_io_t ib = io_plain();
+        ib.limb_mask = allmask & ~fpmask;
+        rc = launch_block_fwd<ArithInt, 14>(c, (const u64*)tmp, dig, rows, A.w, x, ib);
         if (rc) return rc;
     } else {
         hipLaunchKernelGGL(k_ks_digits, row_grid((unsigned)(batch * level * nw), (size_t)c->N), dim3(256), 0, c->stream, ct, dig, c->limbs_dev, A, n, 0u);
