@@ -776,3 +776,30 @@ def test_ckks_encode_decode_match_oracle(N, bits, L, scale):
         ctx.ckks_encode(L, 0, 0, dz.ptr, dout.ptr, 1)                 # scale must be positive
     with pytest.raises(tf.UsageError):
         ctx.ckks_encode(L + 1, 1, 40, dz.ptr, dout.ptr, 1)
+
+
+def test_recycling_allocator_reuses_blocks_without_draining_the_device():
+    """csrc/dev_alloc.h: tfhe_free parks a block behind events on the live contexts' streams, tfhe_malloc hands it out again once
+    they have completed -- same results, far fewer hipMallocs, and tfhe_alloc_trim gives the cache back."""
+    N = 4096
+    qs = H.chain(50, 2, N)
+    ctx, ref = tf.Context(N, qs), ref_cpu.RefCtx(N, qs)
+    rng = np.random.default_rng(7)
+    a = H.rand_residues(rng, qs, (4,), N)
+    want = ref.nntt(a)
+    tf.native.check(tf.native.lib().tfhe_alloc_trim())
+    s0 = tf.native.alloc_stats()
+    for _ in range(200):                                     # allocate / transform / free, never synchronising explicitly
+        d, o = dev(a), tf.DeviceBuffer(a.size)
+        ctx.nntt(d.ptr, o.ptr, 4, 2)
+        del d
+        got = o
+    assert np.array_equal(got.to_numpy(a.shape), want)
+    s1 = tf.native.alloc_stats()
+    assert s1["reuses"] - s0["reuses"] >= 300                # 400 allocations, almost all recycled
+    assert s1["hip_mallocs"] - s0["hip_mallocs"] <= 100
+    del got, o
+    ctx.sync()
+    tf.native.check(tf.native.lib().tfhe_alloc_trim())
+    s2 = tf.native.alloc_stats()
+    assert s2["cached_bytes"] == 0
