@@ -293,7 +293,7 @@ def test_golden_modswitch_galois():
 # ---------------------------------------------------------------------------------------------------
 # K9-K11: keyswitch / rotate
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,bits,Lk", [(32, 40, 4), (2048, 50, 3), (16384, 50, 4), (1 << 15, 50, 3), (1 << 16, 50, 3)])
+@pytest.mark.parametrize("N,bits,Lk", [(32, 40, 4), (2048, 50, 3), (8192, 50, 4), (16384, 50, 4), (1 << 15, 50, 3), (1 << 16, 50, 3)])
 @pytest.mark.parametrize("special", [True, False])
 def test_keyswitch_matches_oracle(N, bits, Lk, special):
     qs = H.chain(bits, Lk, N)
@@ -803,3 +803,26 @@ def test_recycling_allocator_reuses_blocks_without_draining_the_device():
     tf.native.check(tf.native.lib().tfhe_alloc_trim())
     s2 = tf.native.alloc_stats()
     assert s2["cached_bytes"] == 0
+
+
+@pytest.mark.parametrize("special", [True, False])
+def test_fused_keyswitch_at_2_13_many_items(special):
+    """N = 2^13 on the 256 x 32 geometry: the fused key switch with two workgroups per CU walking several (ciphertext, limb)
+    items each, against the one-operation-per-launch path on the whole batch and the oracle on a sub-batch."""
+    N, Lk, batch = 1 << 13, 7, 200
+    qs = H.chain(50, Lk, N)
+    level = Lk - 1 if special else Lk
+    ctx, ref = tf.Context(N, qs), ref_cpu.RefCtx(N, qs)
+    rng = np.random.default_rng(13 + special)
+    evk = H.uniform_evk(rng, qs, Lk, N)
+    ct = H.rand_residues(rng, qs[:level], (batch, 3), N)
+    devk, dct = dev(evk), dev(ct)
+    out, out3 = tf.DeviceBuffer(batch * 2 * level * N), tf.DeviceBuffer(batch * 2 * level * N)
+    ctx.keyswitch(Lk, level, special, devk.ptr, Lk, dct.ptr, 3, out.ptr, batch)
+    ctx.set_ntt_variant(3)
+    ctx.keyswitch(Lk, level, special, devk.ptr, Lk, dct.ptr, 3, out3.ptr, batch)
+    ctx.set_ntt_variant(0)
+    got = out.to_numpy((batch, 2, level, N))
+    assert np.array_equal(got, out3.to_numpy(got.shape))
+    pick = [0, 99, batch - 1]
+    assert np.array_equal(got[pick], ref.keyswitch(level, special, evk, ct[pick]))

@@ -781,6 +781,10 @@ static bool ks_fused14(const tfhe_ctx* c, int Lk, int level, int special) {
     if (special) w.idx[level] = Lk - 1;
     if (c->variant != 0) return false;
     if (c->logN == 14) return sel_fp(c, w, 0);
+    if (c->logN == 13) {  // the 256 x 32 geometry: same fused kernel, two workgroups per CU
+        static const bool on = !(getenv("TFHE_FUSED13") && getenv("TFHE_FUSED13")[0] == '0');
+        return on && sel_fp(c, w, 0);
+    }
     return c->logN == 15 && level >= 2 && sel_fp(c, w, 1);  // k_ks_fused_sub
 }
 // pre-lifted c[end] rows (centred doubles from the BFV contraction) are understood by k_ks_fused only
@@ -945,24 +949,36 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
     const u32 n = (u32)c->N;
     const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
     int rc;
-    if (evd && c->logN == 14) {  // ks_fused14
+    if (evd && (c->logN == 14 || c->logN == 13)) {  // ks_fused14
         // everything in one kernel: digit lift, forward transforms, key inner product and the two inverse transforms;
         // with the special prime the transformed sums go to S and the contraction kernel finishes (modulusraising.jl:42)
-        constexpr int LOGT = logt_for(14);
-        const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
-        auto fk = prelifted ? k_ks_fused<ArithFp, 14, LOGT, true> : k_ks_fused<ArithFp, 14, LOGT, false>;
-        static bool fattr_set = false;
-        if (!fattr_set) {
-            rc = set_lds(k_ks_fused<ArithFp, 14, LOGT, true>, lds);
-            if (!rc) rc = set_lds(k_ks_fused<ArithFp, 14, LOGT, false>, lds);
-            if (rc) return rc;
-            fattr_set = true;
-        }
         const unsigned items = (unsigned)(batch * nw);
-        const unsigned grid = std::min(items, (unsigned)c->num_cus);
-        prof_begin(c, (int64_t)items * (level + 2));  // limb transforms inside this launch: `level` forward + 2 inverse per item
-        hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, special ? S : out, c->limbs_dev, A, Lk, items);
-        prof_end(c);
+        if (c->logN == 14) {
+            constexpr int LOGT = logt_for(14);
+            const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
+            auto fk = prelifted ? k_ks_fused<ArithFp, 14, LOGT, true> : k_ks_fused<ArithFp, 14, LOGT, false>;
+            static bool fattr_set = false;
+            if (!fattr_set) {
+                rc = set_lds(k_ks_fused<ArithFp, 14, LOGT, true>, lds);
+                if (!rc) rc = set_lds(k_ks_fused<ArithFp, 14, LOGT, false>, lds);
+                if (rc) return rc;
+                fattr_set = true;
+            }
+            const unsigned grid = std::min(items, (unsigned)c->num_cus);
+            prof_begin(c, (int64_t)items * (level + 2));  // limb transforms inside this launch: `level` forward + 2 inverse per item
+            hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, special ? S : out, c->limbs_dev, A, Lk, items);
+            prof_end(c);
+        } else {  // N = 2^13: 256 threads x 32 elements, 65 KiB of LDS: two workgroups per CU
+            constexpr int LOGT = logt_for(13);
+            const size_t lds = (size_t)lds_words<13, LOGT>() * 8;
+            auto fk = k_ks_fused<ArithFp, 13, LOGT, false>;
+            static bool fattr13_set = false;
+            if (!fattr13_set) { rc = set_lds(fk, lds); if (rc) return rc; fattr13_set = true; }
+            const unsigned grid = std::min(items, 2u * (unsigned)c->num_cus);
+            prof_begin(c, (int64_t)items * (level + 2));
+            hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, special ? S : out, c->limbs_dev, A, Lk, items);
+            prof_end(c);
+        }
         HIP_TRY(hipGetLastError());
         if (!special) return TFHE_OK;
         rescale_arg_t ra;
@@ -1044,7 +1060,7 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
         KA.w.n = nw;
         for (int j = 0; j < level; j++) KA.w.idx[j] = j;
         if (special) KA.w.idx[level] = Lk - 1;
-        hipLaunchKernelGGL(k_evk_to_f64, row_grid((unsigned)(level * 2 * nw), N), dim3(256), 0, c->stream, evk, evd, c->limbs_dev, KA, Lk, (u32)N, c->logN == 14 ? 1 : 0);
+        hipLaunchKernelGGL(k_evk_to_f64, row_grid((unsigned)(level * 2 * nw), N), dim3(256), 0, c->stream, evk, evd, c->limbs_dev, KA, Lk, (u32)N, c->logN <= 14 ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
     for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
@@ -1102,7 +1118,7 @@ int tfhe_rotate_many(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
     }
     const int nw = special ? level + 1 : level, polys = 2;
     const size_t N = (size_t)c->N;
-    if (!prepared && c->logN == 14 && ks_fused14(c, Lk, level, special)) {
+    if (!prepared && c->logN <= 14 && ks_fused14(c, Lk, level, special)) {
         // N = 2^14 on fp64-size moduli: the fused key switch (digits never leave the registers) beats the hoisted three-kernel
         // path (measured 126 k against 110 k rotations/s at 6 limbs + special prime) -- same bits either way
         for (int r = 0; r < n_rot; r++) {
