@@ -898,11 +898,21 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
-    if (c->logN == 16 && c->variant == 0 && sel_fp(c, A.w, 2) && level >= 2 && (((uintptr_t)S | (uintptr_t)tbuf) & 15u) == 0) {
+    u32 fpm = 0;
+    for (int j = 0; j < nw; j++)
+        if (c->limbs_host[A.w.idx[j]].Wd) fpm |= 1u << j;
+    if (c->logN == 16 && c->variant == 0 && fpm != 0 && level >= 2 && (((uintptr_t)S | (uintptr_t)tbuf) & 15u) == 0) {
         // N = 2^16: the paired sub-block inverse into the (now free) digit buffer, then the two inverse top stages together with
-        // the tail (k_ks_top_tail<2>) instead of k_ntt_inv_top<2> + k_ks_rescale_add / k_ks_add_ct
-        rc = launch_subpair<ArithFp>(c, true, S, tbuf, batch * 2 * nw, A.w, 2, 0u);
+        // the tail (k_ks_top_tail<2>) instead of k_ntt_inv_top<2> + k_ks_rescale_add / k_ks_add_ct.  Rings of mixed modulus sizes:
+        // the larger limbs' sub-blocks come from the u64 block kernel (same sub-block layout, lazy [0, 2q) outputs).
+        rc = launch_subpair<ArithFp>(c, true, S, tbuf, batch * 2 * nw, A.w, 2, fpm == amask ? 0u : fpm);
         if (rc) return rc;
+        if (fpm != amask) {
+            ntt_io_t iw = io_plain();
+            iw.limb_mask = amask & ~fpm;
+            rc = launch_block_inv<ArithInt, 14>(c, S, tbuf, batch * 2 * nw, A.w, 2, iw);
+            if (rc) return rc;
+        }
         rescale_arg_t ra;
         memset(&ra, 0, sizeof ra);
         if (special) {
