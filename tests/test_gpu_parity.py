@@ -826,3 +826,26 @@ def test_fused_keyswitch_at_2_13_many_items(special):
     assert np.array_equal(got, out3.to_numpy(got.shape))
     pick = [0, 99, batch - 1]
     assert np.array_equal(got[pick], ref.keyswitch(level, special, evk, ct[pick]))
+
+
+@pytest.mark.parametrize("logn", [11, 12, 14])
+def test_galois_many_rows_lds_scatter_path(logn):
+    """apply_galois_element on enough rows to take the LDS scatter kernel (N <= 2^14), against the gather kernel (NTT variant 3 keeps
+    the one-operation path) on every row and the oracle on a few; several elements incl. conjugation (2N - 1)."""
+    N = 1 << logn
+    qs = H.chain(50, 3, N)
+    ctx, ref = tf.Context(N, qs), ref_cpu.RefCtx(N, qs)
+    rng = np.random.default_rng(logn)
+    count = 200
+    a = H.rand_residues(rng, qs, (count,), N)
+    a[0, :, :3] = [[0, 1, q - 1] for q in qs]
+    da, d1, d2 = dev(a), tf.DeviceBuffer(a.size), tf.DeviceBuffer(a.size)
+    for g in (3, 5, pow(3, N // 4 + 1, 2 * N), 2 * N - 1):
+        ctx.set_ntt_variant(0)
+        ctx.galois(da.ptr, d1.ptr, g, count, 3)
+        ctx.set_ntt_variant(3)
+        ctx.galois(da.ptr, d2.ptr, g, count, 3)
+        got = d1.to_numpy(a.shape)
+        assert np.array_equal(got, d2.to_numpy(a.shape)), g
+        assert np.array_equal(got[[0, 77, count - 1]], ref.galois(g, a[[0, 77, count - 1]])), g
+    ctx.set_ntt_variant(0)

@@ -1132,6 +1132,41 @@ __global__ __launch_bounds__(256) void k_galois(const u64* __restrict__ src, u64
     }
 }
 
+// The same automorphism for rows that fit the LDS (N <= 2^14) in scatter form through the LDS: the row is read with coalesced
+// 16-byte loads, every word is written to LDS position g*i mod N (odd stride: the 32 lanes of a half-wave hit 32 different
+// bank pairs -- conflict-free), and the permuted row is read back linearly and stored with coalesced 16-byte stores.  The
+// gather form above moves 8 scattered bytes per lane and is bound by the texture addresser (about 8 B/clk/CU: 2.9 TB/s);
+// this one streams.  Persistent workgroups, one row at a time; the stores of a row drain under the loads of the next.
+template <int T>
+__global__ __launch_bounds__(T) void k_galois_lds(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                   const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u64 g, u32 n, u32 nrows) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u64 mask2n = 2ull * n - 1;
+    const u32 tid = threadIdx.x, per = n / (2 * T);           // 16-byte pieces per thread (n >= 2 T)
+    for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const u64 q = LT[sel.idx[row % (u32)sel.n]].q;
+        const u64x2_t* s2 = (const u64x2_t*)(src + (size_t)row * n);
+        u64x2_t* d2 = (u64x2_t*)(dst + (size_t)row * n);
+        for (u32 k0 = 0; k0 < per; k0 += 8) {                 // eight pieces in flight per thread
+            u64x2_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k0 + k < per) v[k] = s2[tid + (k0 + k) * T];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k0 + k < per) {
+                    const u64 i = 2ull * (tid + (k0 + k) * T);
+                    const u64 t0 = (g * i) & mask2n, t1 = (g * (i + 1)) & mask2n;
+                    lds[t0 & (n - 1)] = t0 >= n ? negmod(v[k].x, q) : v[k].x;
+                    lds[t1 & (n - 1)] = t1 >= n ? negmod(v[k].y, q) : v[k].y;
+                }
+        }
+        __syncthreads();
+        for (u32 k = 0; k < per; k++) d2[tid + k * T] = *(const u64x2_t*)(lds + 2 * (tid + k * T));
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // keyswitch pieces (rlwe_she.jl:315-347, modulusraising.jl:35-49)
 // ------------------------------------------------------------------------------------------------

@@ -755,6 +755,18 @@ static int do_galois(tfhe_ctx* c, const u64* src, u64* dst, u64 g, int64_t rows,
     u64 ginv = 1;  // inverse modulo 2N by Newton iteration (g odd)
     for (int i = 0; i < 6; i++) ginv = (ginv * (2 - g * ginv)) & (m - 1);
     if (rows == 0) return TFHE_OK;
+    if (c->variant == 0 && c->logN >= 11 && c->logN <= 14 && rows >= (int64_t)c->num_cus / 2 && (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {
+        // rows that fit the LDS, enough of them to fill the chip: scatter through the LDS, coalesced on both sides
+        constexpr int T = 512;
+        const size_t lds = (size_t)c->N * 8;
+        static bool gattr = false;
+        if (!gattr) { int rc = set_lds(k_galois_lds<T>, 128 * 1024); if (rc) return rc; gattr = true; }
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
+        const unsigned grid = (unsigned)std::min<int64_t>(rows, (int64_t)c->num_cus * per_cu);
+        hipLaunchKernelGGL(k_galois_lds<T>, dim3(grid), dim3(T), lds, c->stream, src, dst, c->limbs_dev, sel, g, (u32)c->N, (u32)rows);
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
     hipLaunchKernelGGL(k_galois, row_grid((unsigned)rows, (size_t)c->N), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, ginv, (u32)c->N);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
