@@ -1167,6 +1167,10 @@ __global__ __launch_bounds__(T) void k_galois_lds(const u64* __restrict__ src, u
     }
 }
 
+// (For N = 2^15 / 2^16 a residue-class variant -- the automorphism maps the class i = r (mod 2^X) onto r' = g r as an affine map of
+// the 2^14 class indices, so each class can go through the same LDS scatter with stride-2^X global accesses -- was measured: no
+// gain at 2^15 (30.2 k vs 30.3 k rotations/s on cfg#3) and slower at 2^16 (24.5 k vs 27.4 k): the gather form stays there.)
+
 // ------------------------------------------------------------------------------------------------
 // keyswitch pieces (rlwe_she.jl:315-347, modulusraising.jl:35-49)
 // ------------------------------------------------------------------------------------------------
