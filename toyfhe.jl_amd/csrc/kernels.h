@@ -107,6 +107,34 @@ __device__ __forceinline__ u32 xcd_walk_item(u32 it, u32 b, u32 grid, int x, u32
     const u32 item = (row << x) | (slot & (nsb - 1u));
     return item < nitems ? item : ~0u;
 }
+// Walk of the fused kernels' (ciphertext b, limb j) items, numbered item = b * nb + j.  Workgroup w runs on XCD w & 7, and
+// every XCD has its own 4 MiB L2: with the plain walk (item = it * grid + w) each XCD meets all nb limbs in turn, and the
+// per-limb constants it streams -- four 128 KiB twiddle tables per limb, in the key switch also 2 * level key rows per limb --
+// are 8.5 MB (17 limbs) / 19 MB (keys) per XCD: they miss L2 and come from the Infinity Cache every time (the PMC read
+// traffic of k_bfv_core_fused was 2.2 x its algorithmic bytes).  Here XCD x takes the x-th eighth of the items in LIMB-MAJOR
+// order (at most ceil(nb / 8) + 1 limbs), its workgroups striding through that share.  Returns ~0u past the end.
+// Used by k_bfv_core_fused (+ 1.1 % on the headline).
+#ifndef TFHE_XCD_LIMB
+#define TFHE_XCD_LIMB 1
+#endif
+template <bool ON = true>
+__device__ __forceinline__ u32 xcd_limb_niter(u32 grid, u32 nitems) {
+    if (!ON || !TFHE_XCD_LIMB || (grid & 7u)) return (nitems + grid - 1) / grid;
+    const u32 per = (nitems + 7u) >> 3, nslots = grid >> 3;
+    return (per + nslots - 1) / nslots;
+}
+template <bool ON = true>
+__device__ __forceinline__ u32 xcd_limb_walk(u32 it, u32 wg, u32 grid, u32 nb, u32 nitems) {
+    if (!ON || !TFHE_XCD_LIMB || (grid & 7u)) {
+        const u32 item = it * grid + wg;
+        return item < nitems ? item : ~0u;
+    }
+    const u32 per = (nitems + 7u) >> 3, nslots = grid >> 3, xcd = wg & 7u, slot = wg >> 3;
+    const u32 k = it * nslots + slot, idx = xcd * per + k;  // position in this XCD's share / in limb-major order
+    if (k >= per || idx >= nitems) return ~0u;
+    const u32 B = nitems / nb, j = idx / B, b = idx - j * B;
+    return b * nb + j;
+}
 template <class A, int LOGB, int LOGT, int IOMODE>
 __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_block(const u64* __restrict__ src, u64* __restrict__ dst,
                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
@@ -1306,6 +1334,23 @@ __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk
     }
 }
 
+#ifdef TFHE_KS_TRACE  // design aid (tools/ks_trace.py): 100 MHz stamps of workgroup 0's phases in the fused key switch
+__device__ unsigned long long tfhe_kst[4096];
+__device__ unsigned tfhe_kst_n;
+__device__ __forceinline__ void kst(unsigned tag) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned n = tfhe_kst_n;
+        if (n < 4096) {
+            tfhe_kst[n] = ((unsigned long long)tag << 56) | (__builtin_amdgcn_s_memrealtime() & ((1ull << 56) - 1));
+            tfhe_kst_n = n + 1;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+#else
+#define kst(tag) ((void)0)
+#endif
 // ---- shared pieces of the fused kernels: a forward transform that ends in registers (last pass's natural-order map)
 // and an inverse transform that starts from registers in that same map ----
 template <class A, int LOGB, int LOGT, bool PRELIFT = false>
@@ -1316,7 +1361,12 @@ __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, con
     const u32 tid = fresh_tid();
     {
         u64 raw[E];
+#ifdef TFHE_ABL_NOROWS  // design aid: operands from arithmetic (wrong results, no row traffic)
+#pragma unroll
+        for (int i = 0; i < E; i++) { raw[i] = (u64)(tid * 131u + (u32)i * 7919u) + (u64)(size_t)grow; pin_vgpr(raw[i]); }
+#else
         fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, grow, tid);
+#endif
         if (!first) __syncthreads();  // the previous transform's last pass has read LDS
         first = false;
         if constexpr (PRELIFT) {
@@ -1335,13 +1385,20 @@ __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, con
         fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
     }
     __syncthreads();
+    kst(2);
     ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
     __syncthreads();
+    kst(3);
     {
         u64 r3[E];
         fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(r3, lds, nullptr, tid);
         fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, 1u);
     }
+#ifdef TFHE_KS_TRACE
+#pragma unroll
+    for (int i = 0; i < E; i++) pin_vgpr(v[i]);
+#endif
+    kst(4);
 }
 // inverse transform of elements held in the forward-last-pass register map (v is reduced here and consumed); result
 // (+ addend) to gdst
@@ -1415,7 +1472,13 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
     const u32 level = (u32)KA.level, polys = (u32)KA.polys, nw = (u32)KA.nw;
     const u32 add_s = polys == 3 ? 2u : 1u;
     bool first = true;
-    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+#ifndef TFHE_XCD_KS  // measured: nothing on the headline's key switch, - 6 % on a 7-limb one (one limb per XCD: its 32 CUs then
+#define TFHE_XCD_KS 0  // read the same key rows in step, through the same L2 channels) -- the plain walk stays
+#endif
+    const u32 niter = xcd_limb_niter<TFHE_XCD_KS>(gridDim.x, nitems);
+    for (u32 it = 0; it < niter; it++) {
+        const u32 item = xcd_limb_walk<TFHE_XCD_KS>(it, blockIdx.x, gridDim.x, nw, nitems);
+        if (item == ~0u) break;
         const u32 b = item / nw, j = item % nw;
         const ntt_limb_t& Lj = LT[KA.w.idx[j]];
         const typename A::ctx C = A::make(Lj);
@@ -1431,6 +1494,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
             lf.half = lf.qi >> 1;
             const u64* grow = ct + ((size_t)((b * polys + polys - 1) * level + i) << LOGB);
             typename A::elem v[E];
+            kst(1);
             fused_fwd_to_regs<A, LOGB, LOGT, PRELIFT>(lds, grow, C, first, v, &lf);
             // multiply-accumulate with the key: component 1 (masked) feeds out_0, component 0 (mask) feeds out_1
             const u64* e_mask = evd + ((((size_t)i * 2 + 0) * nw + j) << LOGB);    // key words as doubles (k_evk_to_f64)
@@ -1443,7 +1507,11 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
                 for (int r = 0; r < G3::R; r++) {
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
                     const int e = u * G3::R + r;
+#ifdef TFHE_ABL_NOKEYS  // design aid: key words from arithmetic (wrong results, no key traffic)
+                    const typename A::tw k1{(double)(nat | 1u) * 4097.0 + C.pinv}, k0{(double)(nat | 3u) * 257.0 + C.pinv};
+#else
                     const typename A::tw k1{A::from_lds(e_masked[nat])}, k0{A::from_lds(e_mask[nat])};
+#endif
                     // range: y reduced to |y| <= p/2, so every term is <= (1/2 + 0.75 a) p = 0.69 p and eight of them stay
                     // below the 7.9 p exactness limit (fp64arith.h); the accumulators are swept every eighth digit
                     const double y = fp_reduce(v[e], C.p, C.pinv);
@@ -1460,12 +1528,19 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
             }
         }
         // inverse transforms of the two accumulators; the first pass takes them from registers (same natural-order map)
+#ifdef TFHE_KS_TRACE
+#pragma unroll
+        for (int e = 0; e < E; e++) { pin_vgpr(acc[0][e]); pin_vgpr(acc[1][e]); }
+#endif
+        kst(5);
 #pragma unroll
         for (int sidx = 0; sidx < 2; sidx++) {
+            if (sidx) kst(6);
             const u64* addend = (!KA.special && (u32)sidx < add_s) ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : nullptr;
             u64* gdst = out + ((size_t)((b * 2 + sidx) * nw + j) << LOGB);
             fused_inv_from_regs<A, LOGB, LOGT, false>(lds, acc[sidx], gdst, C, addend);  // N^-1 is in the key rows (k_evk_to_f64)
         }
+        kst(7);
     }
 }
 
@@ -1635,7 +1710,10 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
     const u32 nb = (u32)sel.n;
     u64* const srow = scratch + ((size_t)blockIdx.x << LOGB);
     bool first = true;
-    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const u32 niter = xcd_limb_niter(gridDim.x, nitems);
+    for (u32 it = 0; it < niter; it++) {
+        const u32 item = xcd_limb_walk(it, blockIdx.x, gridDim.x, nb, nitems);
+        if (item == ~0u) break;
         const u32 b = item / nb, j = item % nb;
         const typename A::ctx C = A::make(LT[sel.idx[j]]);
         const size_t r0 = ((size_t)(b * 2 + 0) * nb + j) << LOGB, r1 = ((size_t)(b * 2 + 1) * nb + j) << LOGB;

@@ -1488,3 +1488,13 @@ int tfhe_event_elapsed_ms(void* a, void* b, float* ms) {
 
 #include "bfv_api.inc"
 #include "comm_api.inc"
+
+#ifdef TFHE_KS_TRACE
+extern "C" int tfhe_debug_kstrace(unsigned long long* out, unsigned* n, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(tfhe_kst), sizeof(unsigned long long) * 4096);
+    hipMemcpyFromSymbol(n, HIP_SYMBOL(tfhe_kst_n), sizeof(unsigned));
+    if (reset) { unsigned z = 0; hipMemcpyToSymbol(HIP_SYMBOL(tfhe_kst_n), &z, sizeof z); }
+    return 0;
+}
+#endif

@@ -71,11 +71,12 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(_SO):
-        raise HipError(f"{_SO} is missing: the HIP engine was not built "
+    so = os.environ.get("TFHE_HIP_LIB") or _SO   # TFHE_HIP_LIB: another build of the same engine (A/B measurements)
+    if not os.path.exists(so):
+        raise HipError(f"{so} is missing: the HIP engine was not built "
                        "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
     _one_hip_runtime()
-    L = C.CDLL(_SO)
+    L = C.CDLL(so)
     L.tfhe_last_error.restype = C.c_char_p
     vp, i64, i32, u64, sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_size_t
     sig = {
