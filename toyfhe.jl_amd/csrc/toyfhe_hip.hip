@@ -793,7 +793,7 @@ static bool ks_fused14(const tfhe_ctx* c, int Lk, int level, int special) {
     if (special) w.idx[level] = Lk - 1;
     if (c->variant != 0) return false;
     if (c->logN == 14) return sel_fp(c, w, 0);
-    if (c->logN == 13) {  // the 256 x 32 geometry: same fused kernel, two workgroups per CU
+    if (c->logN == 13) {  // the 256 x 32 geometry: same fused kernel (it takes 256 VGPRs + 222 AGPRs: one workgroup per CU)
         static const bool on = !(getenv("TFHE_FUSED13") && getenv("TFHE_FUSED13")[0] == '0');
         return on && sel_fp(c, w, 0);
     }
@@ -990,7 +990,8 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
             prof_begin(c, (int64_t)items * (level + 2));  // limb transforms inside this launch: `level` forward + 2 inverse per item
             hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, special ? S : out, c->limbs_dev, A, Lk, items);
             prof_end(c);
-        } else {  // N = 2^13: 256 threads x 32 elements, 65 KiB of LDS: two workgroups per CU
+        } else {  // N = 2^13: 256 threads x 32 elements, 65 KiB of LDS; 478 registers per thread, so one workgroup per CU is resident
+                  // (capped to two resident workgroups it measured 5 % slower)
             constexpr int LOGT = logt_for(13);
             const size_t lds = (size_t)lds_words<13, LOGT>() * 8;
             auto fk = k_ks_fused<ArithFp, 13, LOGT, false>;
