@@ -65,6 +65,10 @@ int tfhe_ctx_destroy(tfhe_ctx *ctx);
 int tfhe_ctx_psi(const tfhe_ctx *ctx, uint64_t *psi_out /* [L] */);
 int tfhe_ctx_set_stream(tfhe_ctx *ctx, void *hip_stream /* hipStream_t, NULL = library-owned */);
 int tfhe_ctx_sync(tfhe_ctx *ctx);
+/* Device-side ordering between two contexts (each has its own stream): work submitted to `ctx` after this call starts after
+ * everything submitted to `producer` before it.  No host wait.  (The reference is single-threaded and synchronous, so it has
+ * no counterpart; the host mirrors use it where a ciphertext of one ring context meets a key of another, rlwe_she.jl:315.) */
+int tfhe_ctx_wait_for(tfhe_ctx *ctx, tfhe_ctx *producer);
 /* choose the NTT kernel family: 0 = auto (register-blocked LDS kernel; exact-integer fp64 butterflies
  * when every selected modulus is < 2^50 + 2^40, u64 Shoup butterflies otherwise), 1 = force the generic
  * radix-2 kernel, 2 = force the u64 register-blocked kernel, 3 = fp64 kernels one operation per launch: no fused

@@ -184,6 +184,38 @@ def test_ckks_modraise_keyswitch_and_rotate():
         tf.keyswitch(ek, tf.CipherText(params, c.cs + c.cs))        # 4 components, rlwe_she.jl:318
 
 
+def test_keyswitch_across_two_contexts_is_ordered_on_the_device():
+    """A ciphertext whose ring lives in ANOTHER context (same moduli: its own stream, tables, workspaces) key-switched with a
+    key of the first: the consumer context is ordered after the producer by tfhe_ctx_wait_for (no host wait), and the result is
+    bit-identical to the same-context call.  Large enough that the producer's work is still in flight when the key switch is
+    submitted."""
+    N = 1 << 13
+    R = tf.NegacyclicRing(N, chain(2**50 + 1, 4, N))
+    params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    rng = np.random.default_rng(11)
+    kp = tf.keygen(rng, params)
+    ek = tf.make_eval_key(rng, kp.priv.secret, kp.priv)
+    Rc = params.R_cipher()
+    batch = 24
+    vals = np.repeat((np.arange(1, N // 2 + 1) / N).astype(complex)[None], batch, axis=0)
+    c = tf.encrypt(rng, kp, tf.ckks_encode(vals, Rc, 2**40), scale=2**40)
+    want = [x.to_numpy() for x in tf.keyswitch(ek, c).cs]
+    R2 = tf.NegacyclicRing(N, Rc.moduli, Rc.psi)                      # a second context over the ciphertext moduli
+    assert R2.ctx is not Rc.ctx
+    for _ in range(3):
+        # produce the components on R2's stream right before the call: upload, forward and inverse transform (a round trip)
+        cs2 = []
+        for x in c.cs:
+            e = tf.RingElement.from_residues(R2, x.to_numpy())
+            cs2.append(tf.RingElement(R2, None, e.coeffs_dual(), e.batch))     # dual only: keyswitch pulls coeffs_primal() on R2
+        got = tf.keyswitch(ek, tf.CipherText(params, cs2, c.scale))
+        for g, w in zip(got.cs, want):
+            assert np.array_equal(g.to_numpy(), w)
+    with pytest.raises(tf.UsageError):
+        R3 = tf.NegacyclicRing(N, chain(2**50 + 1, 5, N)[1:4])        # other moduli: refused, not mis-switched
+        tf.keyswitch(ek, tf.CipherText(params, [tf.RingElement.from_residues(R3, np.zeros((batch, 3, N), np.uint64))] * 2, c.scale))
+
+
 def test_ckks_mul_rescale_pipeline():
     """the encrypted_mnist-style step: ct*ct -> relinearise (special prime) -> rescale."""
     N = 64

@@ -592,6 +592,19 @@ int tfhe_ctx_sync(tfhe_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return TFHE_OK;
 }
+// Work submitted to `c` after this call starts after everything submitted to `producer` before it (one recorded event, no
+// host wait): the way two contexts with their own streams hand device buffers to each other.
+int tfhe_ctx_wait_for(tfhe_ctx* c, tfhe_ctx* producer) {
+    if (!c || !producer) return fail(TFHE_E_BADARG, "null context");
+    if (c == producer || c->stream == producer->stream) return TFHE_OK;
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, producer->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
+    hipEventDestroy(ev);  // deferred by the runtime until the event has completed
+    if (e != hipSuccess) return fail(TFHE_E_HIP, "tfhe_ctx_wait_for: %s", hipGetErrorString(e));
+    return TFHE_OK;
+}
 int tfhe_ctx_set_ntt_variant(tfhe_ctx* c, int v) {
     if (!c || v < 0 || v > 3) return fail(TFHE_E_BADARG, "variant must be 0, 1, 2 or 3");
     c->variant = v;

@@ -62,6 +62,8 @@ function modring(::Type{T}, N::Integer) where {T<:CRTEncoded}
     end
 end
 sync(r::HipRing) = check(ccall((:tfhe_ctx_sync, lib), Cint, (Ptr{Cvoid},), r.handle))
+# device-side ordering between two contexts (no host wait): r's later work runs after what `producer` has been given so far
+wait_for(r::HipRing, producer::HipRing) = check(ccall((:tfhe_ctx_wait_for, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), r.handle, producer.handle))
 
 # ---- device storage: [L][N] UInt64 residues, limb-major like StructArray field arrays (crt.jl:150-156) -------------
 mutable struct HipVector{T} <: AbstractVector{T}

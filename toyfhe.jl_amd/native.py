@@ -87,6 +87,7 @@ def lib():
         "tfhe_ctx_psi": [vp, u64p],
         "tfhe_ctx_set_stream": [vp, vp],
         "tfhe_ctx_sync": [vp],
+        "tfhe_ctx_wait_for": [vp, vp],
         "tfhe_ctx_set_ntt_variant": [vp, i32],
         "tfhe_malloc": [sz, C.POINTER(vp)],
         "tfhe_free": [vp],
@@ -149,7 +150,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "tfhe_last_error", "tfhe_device_count", "tfhe_set_device", "tfhe_ctx_create", "tfhe_ctx_destroy", "tfhe_ctx_psi",
-    "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
+    "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_wait_for", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
     "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_pack_poly", "tfhe_unpack_poly", "tfhe_broadcast_poly", "tfhe_alloc_stats", "tfhe_alloc_trim", "tfhe_comm_id", "tfhe_comm_create", "tfhe_comm_destroy", "tfhe_gather", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
     "tfhe_mul", "tfhe_mad", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
     "tfhe_keyswitch", "tfhe_rotate", "tfhe_rotate_many", "tfhe_galois_key_prepare", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
@@ -257,6 +258,10 @@ class Context:
 
     def sync(self):
         check(lib().tfhe_ctx_sync(self.h))
+
+    def wait_for(self, producer: "Context"):
+        """Order this context's later work after everything already submitted to `producer` (device-side, no host wait)."""
+        check(lib().tfhe_ctx_wait_for(self.h, producer.h))
 
     def set_stream(self, stream_ptr):
         check(lib().tfhe_ctx_set_stream(self.h, stream_ptr))

@@ -189,6 +189,7 @@ class RingElement:
     def to_numpy(self, domain="primal") -> np.ndarray:
         buf = self.coeffs_primal() if domain == "primal" else self.coeffs_dual()
         shape = (self.ring.L, self.ring.N) if self.batch is None else (self.batch, self.ring.L, self.ring.N)
+        self.ring.ctx.sync()        # the one host wait of the device path (a caller's stream may be non-blocking)
         return buf.to_numpy(shape)
 
     def to_ints(self):

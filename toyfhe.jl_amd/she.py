@@ -534,7 +534,8 @@ def _unpack(buf, ring, n, P, batch, primal=True, ctx=None):
         o = DeviceBuffer(n * sz)
         native.check(lib.tfhe_unpack_poly(ctx.h, o.ptr, buf.ptr, P, p, sz, n))
         outs.append(RingElement(ring, o, None, batch) if primal else RingElement(ring, None, o, batch))
-    ctx.sync()  # `buf` may be released by the caller as soon as we return
+    # no host wait: `buf` may be released by the caller as soon as we return -- the allocator parks a released block until
+    # the work submitted so far on every context stream has finished (tfhe_free, dev_alloc.h)
     return tuple(outs)
 
 
@@ -614,7 +615,7 @@ def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
         raise UsageError("ciphertext and key belong to different rings")
     sz = level * ring.N
     if ring.ctx is not keyring.ctx:
-        ring.ctx.sync()                                    # the components were produced on the ciphertext ring's stream
+        keyring.ctx.wait_for(ring.ctx)                     # the components were produced on the ciphertext ring's stream
     ct = _pack([x.coeffs_primal() for x in c.cs], ring, n, ctx=keyring.ctx)
     out = DeviceBuffer(n * 2 * sz)
     if _galois is None:
@@ -654,7 +655,7 @@ def rotate_many(gks, c: CipherText):
     if ring.ctx is not keyring.ctx:
         if ring.N != keyring.N or ring.moduli != keyring.moduli[:level] or ring.psi != keyring.psi[:level]:
             raise UsageError("ciphertext and key belong to different rings")
-        ring.ctx.sync()
+        keyring.ctx.wait_for(ring.ctx)
     sz = level * ring.N
     ct = _pack([x.coeffs_primal() for x in c.cs], ring, n, ctx=keyring.ctx)
     out = DeviceBuffer(len(gks) * n * 2 * sz)
@@ -721,8 +722,7 @@ def ckks_encode(slots, ring: NegacyclicRing, scale) -> RingElement:
     dz = DeviceBuffer.from_numpy(z2.view(np.uint64))
     out = DeviceBuffer(z2.shape[0] * ring.L * ring.N)
     ring.ctx.ckks_encode(ring.L, mant, exp2, dz.ptr, out.ptr, z2.shape[0])
-    ring.ctx.sync()
-    return RingElement(ring, out, None, batch)
+    return RingElement(ring, out, None, batch)             # (dz is parked by the allocator until the kernels have read it)
 
 
 def ckks_decode(el: RingElement, scale) -> np.ndarray:
@@ -734,6 +734,7 @@ def ckks_decode(el: RingElement, scale) -> np.ndarray:
     n = el.count
     out = DeviceBuffer(n * ring.N)                         # N/2 complex doubles = N words per plaintext
     ring.ctx.ckks_decode(ring.L, mant, exp2, el.coeffs_primal().ptr, out.ptr, n)
+    ring.ctx.sync()
     z = out.to_numpy().view(np.complex128).reshape(n, ring.N // 2)
     return z if el.batch is not None else z[0]
 
