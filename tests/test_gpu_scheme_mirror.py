@@ -317,6 +317,13 @@ def test_encrypted_mnist_reference_model_at_reference_parameters():
     assert rng_ > 1.0 and err < 1e-3 and agree == 1.0, (err, rng_, agree)
 
 
+def test_encrypted_mnist_with_hoisted_rotations():
+    """the same pipeline with the 63 rotations of each matrix product taken from ONE digit decomposition (tfhe_rotate_many,
+    63 Galois keys for the steps B .. 63 B) instead of 63 chained rotations: same logits within the CKKS error."""
+    err, rng_, agree = _mnist().run(logn=13, seed=1, verbose=False, model="reference", batches=2, hoisted=True)
+    assert rng_ > 1.0 and err < 1e-3 and agree == 1.0, (err, rng_, agree)
+
+
 def test_encrypted_mnist_reference_model_at_2_16():
     """BASELINE config #5 as stated (N = 2^16, 512 images per ciphertext) on the same model and moduli chain; the reference's
     floor rescale leaves a bias that grows with N (see test_cfg3_ckks_rotate_decrypts_at_full_degree), hence the looser bound."""
