@@ -216,6 +216,32 @@ def test_keyswitch_across_two_contexts_is_ordered_on_the_device():
         tf.keyswitch(ek, tf.CipherText(params, [tf.RingElement.from_residues(R3, np.zeros((batch, 3, N), np.uint64))] * 2, c.scale))
 
 
+def test_scheme_layer_on_a_callers_non_blocking_stream():
+    """tfhe_ctx_set_stream with a torch side stream (created non-blocking: the null stream's copies do not wait for it): the
+    scheme layer submits everything to that stream without host waits and synchronises it only where results are read."""
+    torch = pytest.importorskip("torch")
+    N = 1 << 12
+    R = tf.NegacyclicRing(N, chain(2**40 + 1, 3, N))               # rescaling by a 40-bit prime keeps the scale at 2^40
+    side = torch.cuda.Stream()
+    R.ctx.set_stream(side.cuda_stream)
+    try:
+        params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+        rng = np.random.default_rng(21)
+        kp = tf.keygen(rng, params)
+        ek = tf.keygen_evalmult(rng, kp.priv)
+        gk = tf.keygen_galois(rng, kp.priv, steps=1)
+        vals = (np.arange(1, N // 2 + 1) / N).astype(complex)
+        scale = 2**40
+        c = tf.encrypt(rng, kp, tf.ckks_encode(vals, params.R_cipher(), scale), scale=scale)
+        for _ in range(4):                                       # a chain of dependent device calls, no host wait in between
+            c2 = tf.rotate(gk, c)
+        sq = tf.modswitch(tf.keyswitch(ek, c * c))
+        assert np.abs(tf.ckks_decode(tf.decrypt(kp, c2), c2.scale) - np.roll(vals, 1)).max() < 1e-6
+        assert np.abs(tf.ckks_decode(tf.decrypt(kp, sq), sq.scale) - vals * vals).max() < 1e-5
+    finally:
+        R.ctx.set_stream(None)
+
+
 def test_ckks_mul_rescale_pipeline():
     """the encrypted_mnist-style step: ct*ct -> relinearise (special prime) -> rescale."""
     N = 64
