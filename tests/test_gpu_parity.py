@@ -852,3 +852,62 @@ def test_galois_many_rows_lds_scatter_path(logn):
         assert np.array_equal(got, d2.to_numpy(a.shape)), g
         assert np.array_equal(got[[0, 37, count - 1]], ref.galois(g, a[[0, 37, count - 1]])), g
     ctx.set_ntt_variant(0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# randomised shapes: degree, limb count, modulus sizes (mixed 30..61 bit), batch, level, special prime, component count
+# drawn from a seeded generator -- every operation of the path against the C oracle, bit for bit
+# ---------------------------------------------------------------------------------------------------
+def _random_ring(rng, logn, L):
+    N = 1 << logn
+    qs, used = [], set()
+    for _ in range(L):
+        bits = int(rng.choice([30, 36, 40, 45, 50, 50, 55, 60, 61]))
+        q = tf.nextprime(2**bits + 1 + 2 * N * int(rng.integers(0, 50)), 1, 2 * N)
+        while q in used:
+            q = tf.nextprime(q + 2 * N, 1, 2 * N)
+        used.add(q)
+        qs.append(q)
+    return N, qs
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes_against_the_oracle(seed):
+    rng = np.random.default_rng(9000 + seed)
+    logn = int(rng.choice([3, 6, 9, 10, 11, 12, 13, 14, 15, 16], p=[.05, .05, .05, .1, .1, .1, .15, .2, .1, .1]))
+    L = int(rng.integers(2, 7 if logn <= 14 else 5))
+    N, qs = _random_ring(rng, logn, L)
+    ctx, ref = tf.Context(N, qs), ref_cpu.RefCtx(N, qs)
+    batch = int(rng.integers(1, 6 if logn >= 15 else 12))
+    # transforms (all limbs, then a random limb subset), round trip
+    a = H.rand_residues(rng, qs, (batch,), N)
+    f = run_ntt(ctx, a)
+    assert np.array_equal(f, ref.nntt(a)), ("nntt", logn, qs)
+    assert np.array_equal(run_ntt(ctx, f, inverse=True), a), ("inntt", logn, qs)
+    idx = sorted(rng.choice(L, size=int(rng.integers(1, L + 1)), replace=False).tolist())
+    sub = np.ascontiguousarray(a[:, idx])
+    assert np.array_equal(run_ntt(ctx, sub, idx=idx), ref.nntt(sub, idx=idx)), ("nntt subset", idx)
+    # rescale (drop the last limb) and a Galois automorphism
+    g = int(rng.choice([3, 5, 2 * N - 1, pow(3, int(rng.integers(1, N)), 2 * N)]))
+    da = dev(a)
+    dg = tf.DeviceBuffer(a.size)
+    ctx.galois(da.ptr, dg.ptr, g, batch, L)
+    assert np.array_equal(dg.to_numpy(a.shape), ref.galois(g, a)), ("galois", g)
+    dr = tf.DeviceBuffer(batch * (L - 1) * N)
+    ctx.rescale(da.ptr, dr.ptr, batch, L)
+    assert np.array_equal(dr.to_numpy((batch, L - 1, N)), ref.modswitch(a)), "rescale"
+    # key switch / rotation at a random level, with and without the special prime, 2 or 3 components
+    special = bool(rng.integers(0, 2))
+    maxlevel = L - 1 if special else L
+    level = int(rng.integers(1, maxlevel + 1))
+    polys = int(rng.choice([2, 3]))
+    evk = H.uniform_evk(rng, qs, L, N)
+    ct = H.rand_residues(rng, qs[:level], (batch, polys), N)
+    devk, dct, dout = dev(evk), dev(ct), tf.DeviceBuffer(batch * 2 * level * N)
+    ctx.keyswitch(L, level, special, devk.ptr, L, dct.ptr, polys, dout.ptr, batch)
+    assert np.array_equal(dout.to_numpy((batch, 2, level, N)), ref.keyswitch(level, special, evk, ct)), ("keyswitch", level, special, polys, qs)
+    ct2 = np.ascontiguousarray(ct[:, :2])
+    dct2 = dev(ct2)
+    ctx.rotate(L, level, special, devk.ptr, L, g, dct2.ptr, dout.ptr, batch)
+    rot = ref.galois(g, ct2.reshape(-1, level, N), idx=range(level)).reshape(ct2.shape)
+    assert np.array_equal(dout.to_numpy((batch, 2, level, N)), ref.keyswitch(level, special, evk, rot)), ("rotate", g, level, special)
