@@ -911,3 +911,54 @@ def test_random_shapes_against_the_oracle(seed):
     ctx.rotate(L, level, special, devk.ptr, L, g, dct2.ptr, dout.ptr, batch)
     rot = ref.galois(g, ct2.reshape(-1, level, N), idx=range(level)).reshape(ct2.shape)
     assert np.array_equal(dout.to_numpy((batch, 2, level, N)), ref.keyswitch(level, special, evk, rot)), ("rotate", g, level, special)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_bfv_multiplications_against_the_oracle(seed):
+    """tfhe_bfv_mul_relin on random parameter sets: degree 2^8..2^14, 1..5 limbs of mixed sizes, an extension basis that
+    contains the ciphertext basis (superset) or is disjoint from it, random plaintext modulus, ragged chunks."""
+    rng = np.random.default_rng(7000 + seed)
+    logn = int(rng.choice([8, 10, 11, 12, 13, 14], p=[.1, .1, .15, .15, .2, .3]))
+    N = 1 << logn
+    ns = int(rng.integers(1, 6))
+    t = int(rng.choice([2, 257, 65537, 786433, (1 << 20) + 7]))
+    superset = bool(rng.integers(0, 2))
+    sizes = [int(rng.choice([40, 45, 50, 50, 50, 55, 60])) for _ in range(ns)]
+    uniform50 = bool(rng.integers(0, 2))                          # half of the cases on the fp64-size class (the fused kernels)
+    if uniform50:
+        sizes = [50] * ns
+    qs, used = [], set()
+    for bits in sizes:
+        q = tf.nextprime(2**bits + 1, 1, 2 * N)
+        while q in used:
+            q = tf.nextprime(q + 2 * N, 1, 2 * N)
+        used.add(q); qs.append(q)
+    ext_bits = 50 if uniform50 else int(rng.choice([50, 60]))
+    # extension primes: enough for Qbig >= Q^2 * t * N * 4 (bfv.jl:47-118 sizes it the same way)
+    need = 2 * sum(q.bit_length() for q in qs) + t.bit_length() + logn + 3
+    ext, q = [], tf.nextprime(2**ext_bits + 1, 1, 2 * N)
+    have = sum(x.bit_length() - 1 for x in qs) if superset else 0
+    while have < need:
+        if q not in used:
+            ext.append(q); used.add(q); have += q.bit_length() - 1
+        q = tf.nextprime(q + 2 * N, 1, 2 * N)
+    pb = (qs + ext) if superset else ext
+    rs, rb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, pb)
+    if superset:
+        cbig = tf.Context(N, pb); csmall = cbig
+        plan = tf.BfvPlan(csmall, cbig, t, idx_s=list(range(ns)))
+    else:
+        csmall, cbig = tf.Context(N, qs), tf.Context(N, pb)
+        plan = tf.BfvPlan(csmall, cbig, t)
+    batch = int(rng.integers(1, 7))
+    plan.set_chunk(int(rng.integers(1, batch + 1)))
+    c1, c2 = H.rand_residues(rng, qs, (batch, 2), N), H.rand_residues(rng, qs, (batch, 2), N)
+    evk = H.uniform_evk(rng, qs, ns, N)
+    d1, d2, devk = dev(c1), dev(c2), dev(evk)
+    do3 = tf.DeviceBuffer(batch * 3 * ns * N)
+    plan.mul(d1.ptr, d2.ptr, do3.ptr, batch)
+    prod = ref_cpu.bfv_mul(rs, rb, t, c1, c2)
+    assert np.array_equal(do3.to_numpy((batch, 3, ns, N)), prod), ("mul", logn, qs, pb, t)
+    do2 = tf.DeviceBuffer(batch * 2 * ns * N)
+    plan.mul_relin(devk.ptr, ns, d1.ptr, d2.ptr, do2.ptr, batch)
+    assert np.array_equal(do2.to_numpy((batch, 2, ns, N)), rs.keyswitch(ns, False, evk, prod)), ("mul_relin", logn, qs, pb, t)
