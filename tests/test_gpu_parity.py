@@ -911,6 +911,14 @@ def test_random_shapes_against_the_oracle(seed):
     ctx.rotate(L, level, special, devk.ptr, L, g, dct2.ptr, dout.ptr, batch)
     rot = ref.galois(g, ct2.reshape(-1, level, N), idx=range(level)).reshape(ct2.shape)
     assert np.array_equal(dout.to_numpy((batch, 2, level, N)), ref.keyswitch(level, special, evk, rot)), ("rotate", g, level, special)
+    # hoisted rotations: the same key under two more Galois elements, against the one-by-one rotations
+    gs = [g, int(pow(3, int(rng.integers(1, N)), 2 * N)), 2 * N - 1]
+    many = tf.DeviceBuffer(len(gs) * batch * 2 * level * N)
+    ctx.rotate_many(L, level, special, [devk.ptr] * len(gs), L, gs, dct2.ptr, many.ptr, batch)
+    got = many.to_numpy((len(gs), batch, 2, level, N))
+    for r, gr in enumerate(gs):
+        ctx.rotate(L, level, special, devk.ptr, L, gr, dct2.ptr, dout.ptr, batch)
+        assert np.array_equal(got[r], dout.to_numpy((batch, 2, level, N))), ("rotate_many", gr, level, special)
 
 
 @pytest.mark.parametrize("seed", range(12))
