@@ -142,6 +142,69 @@ __global__ __launch_bounds__(512) void k_mask(const u64* __restrict__ src, u64* 
         if (a1 == 1.2345e301) dst[threadIdx.x] = 1;
     }
 }
+// the same kernel with the item loop unrolled 8 times: ~170 KB of straight-line code per trip (the fused kernels' shape)
+template <int MASK>
+__global__ __launch_bounds__(512) void k_mask_bloat(const u64* __restrict__ src, u64* __restrict__ dst, const ntt_limb_t* __restrict__ LT,
+                                              limb_sel_t sel, u32 nitems) {
+    typedef typename std::conditional<(MASK & 4) != 0, ArithFpNoTw, typename std::conditional<(MASK & 8) != 0, ArithFpUniTw, ArithFp>::type>::type A;
+    constexpr int LOGB = 14, LOGT = 9;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
+    constexpr int E = 1 << (LOGB - LOGT);
+    bool first = true;
+    double acc[2][(MASK & 16) ? E : 1];
+    if (MASK & 16) {
+#pragma unroll
+        for (int i = 0; i < E; i++) acc[0][i] = acc[1][i] = 0.0;
+    }
+#pragma unroll 8
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const typename A::ctx C = A::make(LT[sel.idx[item % (u32)sel.n]]);
+        const u32 tid = fresh_tid();
+        const u64* g = src + ((size_t)item << LOGB);
+        u64 raw[E];
+        typename A::elem v[E];
+        if (MASK & 1) {
+#pragma unroll
+            for (int i = 0; i < E; i++) { raw[i] = (u64)(tid * 131u + (u32)i * 7919u + item); pin_vgpr(raw[i]); }
+        } else {
+            fwd_load_data<LOGB, LOGT, 0, K1, true, false>(raw, lds, g, tid);
+        }
+        if (!first) __syncthreads();
+        first = false;
+        fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u);
+        fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+        __syncthreads();
+        fwd_load_data<LOGB, LOGT, K1, K2, false, false>(raw, lds, nullptr, tid);
+        fwd_compute<A, LOGB, LOGT, K1, K2, false, false, 0>(v, raw, nullptr, C, tid, 1u);
+        __syncthreads();
+        fwd_store<A, LOGB, LOGT, K1, K2, false>(v, lds, nullptr, C, tid, 0, 0u);
+        __syncthreads();
+        fwd_load_data<LOGB, LOGT, K1 + K2, K3, false, true>(raw, lds, nullptr, tid);
+        fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, raw, nullptr, C, tid, 1u);
+        if (MASK & 16) {
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                const double y = fp_reduce(v[i], C.p, C.pinv);
+                acc[0][i] += fp_mulmod_c(y, ftw_t{C.pinv * 3.0 + (double)i}, C.p, C.pinv);
+                acc[1][i] += fp_mulmod_c(y, ftw_t{C.pinv * 5.0 + (double)i}, C.p, C.pinv);
+            }
+        } else if (MASK & 2) {
+            double a1 = 0;
+#pragma unroll
+            for (int i = 0; i < E; i++) a1 += v[i];
+            if (a1 == 1.2345e301) dst[tid] = 1;
+        } else {
+            fwd_store<A, LOGB, LOGT, K1 + K2, K3, true>(v, lds, dst + ((size_t)item << LOGB), C, tid, 0, 0u);
+        }
+    }
+    if (MASK & 16) {
+        double a1 = 0;
+#pragma unroll
+        for (int i = 0; i < E; i++) a1 += acc[0][i] * acc[1][i];
+        if (a1 == 1.2345e301) dst[threadIdx.x] = 1;
+    }
+}
 template <int MASK>
 void runm(const ntt_limb_t* LT, int L, u64* a, u64* b, int rows) {
     limb_sel_t sel; sel.n = L; for (int j = 0; j < L; j++) sel.idx[j] = j;
@@ -157,6 +220,23 @@ void runm(const ntt_limb_t* LT, int L, u64* a, u64* b, int rows) {
     }
     if (MASK & 16) printf("[128 accumulator VGPRs live, +product] ");
     printf("mask: rowloads %s  stores %s  twiddles %-7s  %.2f us per row per CU\n", (MASK & 1) ? "-" : "Y", (MASK & 2) ? "-" : "Y",
+           (MASK & 4) ? "-" : (MASK & 8) ? "uniform" : "Y", best * 1e3 / (rows / 256.0));
+}
+template <int MASK>
+void runb(const ntt_limb_t* LT, int L, u64* a, u64* b, int rows) {
+    limb_sel_t sel; sel.n = L; for (int j = 0; j < L; j++) sel.idx[j] = j;
+    const size_t lds = (size_t)lds_words<14, 9>() * 8;
+    hipFuncSetAttribute((const void*)k_mask_bloat<MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; rep++) {
+        hipEventRecord(e0);
+        for (int it = 0; it < 5; it++) hipLaunchKernelGGL(k_mask_bloat<MASK>, dim3(256), dim3(512), lds, 0, a, b, LT, sel, (u32)rows);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 5 < best) best = ms / 5;
+    }
+    if (MASK & 16) printf("[128 accumulator VGPRs live, +product] ");
+    printf("[item loop unrolled x8] mask: rowloads %s  stores %s  twiddles %-7s  %.2f us per row per CU\n", (MASK & 1) ? "-" : "Y", (MASK & 2) ? "-" : "Y",
            (MASK & 4) ? "-" : (MASK & 8) ? "uniform" : "Y", best * 1e3 / (rows / 256.0));
 }
 template <int MODE>
@@ -203,6 +283,7 @@ int main(int argc, char** argv) {
         runm<0>(dLT, L, a, b, rows); runm<1>(dLT, L, a, b, rows); runm<2>(dLT, L, a, b, rows); runm<3>(dLT, L, a, b, rows);
         runm<4>(dLT, L, a, b, rows); runm<5>(dLT, L, a, b, rows); runm<6>(dLT, L, a, b, rows); runm<7>(dLT, L, a, b, rows);
         runm<16 + 2>(dLT, L, a, b, rows); runm<16 + 3>(dLT, L, a, b, rows); runm<16 + 7>(dLT, L, a, b, rows);
+        runb<0>(dLT, L, a, b, rows); runb<3>(dLT, L, a, b, rows); runb<7>(dLT, L, a, b, rows);
         runm<8>(dLT, L, a, b, rows); runm<9>(dLT, L, a, b, rows); runm<10>(dLT, L, a, b, rows); runm<11>(dLT, L, a, b, rows);
         return 0;
     }
