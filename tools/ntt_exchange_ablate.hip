@@ -8,7 +8,9 @@
 // (10.3 us); row loads alone + 2.1, stores alone + 2.4, both + 5.6, all three 17.7-18 us; the twiddle footprint (1 limb or 8)
 // does not matter; nontemporal hints on the row traffic change nothing; generating the per-thread twiddles from one base
 // per stage (13 loads instead of 61 per thread, + 11 % arithmetic) is slower (18.7), prefetching those bases at row start
-// slower still (20.4).  The row traffic at the copy rate (5.3 TB/s) would take 12.4 us.
+// slower still (20.4).  The row traffic at the copy rate (5.3 TB/s) would take 12.4 us.  Code size is not a factor: with the
+// item loop unrolled 8 times (~170 KB of straight-line code per trip, the fused kernels' shape) the times are the same
+// (10.4 without memory traffic, 17.9 complete); 128 more live VGPRs (two accumulator sets) change nothing either.
 // build (repo root): hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value tools/ntt_exchange_ablate.hip -o tools/bin/ntt_exchange_ablate
 #include <hip/hip_runtime.h>
 #include <cstdio>
