@@ -348,6 +348,9 @@ def test_encrypted_mnist_with_hoisted_rotations():
     63 Galois keys for the steps B .. 63 B) instead of 63 chained rotations: same logits within the CKKS error."""
     err, rng_, agree = _mnist().run(logn=13, seed=1, verbose=False, model="reference", batches=2, hoisted=True)
     assert rng_ > 1.0 and err < 1e-3 and agree == 1.0, (err, rng_, agree)
+    # second pass with the weight plaintexts encoded once by the first (CipherText.mul_plain on pre-encoded ring elements)
+    err2, _, agree2 = _mnist().run(logn=13, seed=1, verbose=False, model="reference", batches=2, hoisted=True, repeat=2)
+    assert err2 < 1e-3 and agree2 == 1.0, (err2, agree2)
 
 
 def test_encrypted_mnist_reference_model_at_2_16():

@@ -373,6 +373,10 @@ class CipherText:
             rem = fr - fl
             scaled = fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2) else 0)   # FixedRational(b).x, ckks.jl:42
             cs = [c * int(scaled) for c in self.cs]
+        elif isinstance(x, RingElement):             # a plaintext the caller has encoded at this ciphertext's scale already
+            if x.ring != self.ring():
+                raise UsageError("pre-encoded plaintext belongs to another ring")
+            cs = [c * x for c in self.cs]
         else:
             re = ckks_encode(np.asarray(x, dtype=np.complex128), self.ring(), self.scale)
             cs = [c * re for c in self.cs]
