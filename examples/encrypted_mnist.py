@@ -79,15 +79,17 @@ def encrypted_matmul(gk, W, x, B, cache=None):
         pt.coeffs_dual()
         cache[key] = pt
         return pt
-    result = x.mul_plain(diag(0))
     if isinstance(gk, (list, tuple)):
-        for k, rotated in enumerate(tf.rotate_many(gk, x), start=1):
-            result = result + rotated.mul_plain(diag(k))
-        return result
-    rotated = x
+        rots = [x] + list(tf.rotate_many(gk, x))
+    else:
+        rots = [x]
+        for k in range(1, n):
+            rots.append(tf.rotate(gk, rots[-1]))
+    if cache is not None:      # plaintexts are ring elements already: the whole accumulation is one device pass per component
+        return tf.CipherText.dot_plain(rots, [diag(k) for k in range(n)])
+    result = rots[0].mul_plain(diag(0))
     for k in range(1, n):
-        rotated = tf.rotate(gk, rotated)
-        result = result + rotated.mul_plain(diag(k))
+        result = result + rots[k].mul_plain(diag(k))
     return result
 
 

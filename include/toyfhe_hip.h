@@ -112,6 +112,12 @@ int tfhe_neg(tfhe_ctx *ctx, const uint64_t *a, uint64_t *dst, int64_t count, int
 int tfhe_mul(tfhe_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
 /* dst = acc + a*b (the `c += x*y` pattern of rlwe_she.jl:257,342-343) */
 int tfhe_mad(tfhe_ctx *ctx, const uint64_t *acc, const uint64_t *a, const uint64_t *b, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
+/* dst = (acc +) sum_{k < n_terms} a[k] .* b[k], every operand [count][limbs][N] (acc may be NULL; dst may alias acc): the
+ * accumulation loop `result += rotated_k * diagonal_k` of the diagonal matrix-vector product (examples/encrypted_mnist/
+ * infer.jl:140-149 -- there one ring multiplication and one ring addition per term, pow2_cyc_rings.jl:167,200-214) in one pass.
+ * a, b: host arrays of n_terms device pointers.  Exact: the same canonical residues as tfhe_mad term by term. */
+int tfhe_dot(tfhe_ctx *ctx, const uint64_t *acc, const uint64_t *const *a, const uint64_t *const *b, int n_terms, uint64_t *dst,
+             int64_t count, int limbs, const int32_t *limb_idx);
 /* scalar_mul (pow2_cyc_rings.jl:177-185): scalar given as residues scal[j] mod q_{limb_idx[j]} (host array) */
 int tfhe_scalar_mul(tfhe_ctx *ctx, const uint64_t *scal, const uint64_t *a, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
 

@@ -854,6 +854,50 @@ def test_galois_many_rows_lds_scatter_path(logn):
     ctx.set_ntt_variant(0)
 
 
+@pytest.mark.parametrize("N,qspec,terms,count", [(64, "40x3", 5, 3), (4096, "mixed", 64, 2), (4096, "61x2", 7, 2), (1 << 13, "50x4", 70, 1),
+                                                  (1 << 16, "mixed", 9, 1)])
+def test_dot_equals_the_term_by_term_sum(N, qspec, terms, count):
+    """tfhe_dot (sum_k a_k .* b_k in one pass, 128-bit lazy sums reduced every 2^(62 - bits(q)) terms) against exact integer
+    arithmetic and against tfhe_mad term by term; > 64 terms take a second launch that accumulates; acc and limb subsets."""
+    if qspec == "mixed":
+        qs = H.chain(60, 1, N) + H.chain(40, 2, N) + [H.chain(60, 2, N)[1]]
+    else:
+        bits, n = qspec.split("x")
+        qs = H.chain(int(bits), int(n), N)
+    L = len(qs)
+    ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(N + terms)
+    a = [H.rand_residues(rng, qs, (count,), N) for _ in range(terms)]
+    b = [H.rand_residues(rng, qs, (count,), N) for _ in range(terms)]
+    for l in range(L):                                             # worst case for the lazy sums: every product (q - 1)^2
+        for k in range(terms):
+            a[k][0, l, :3] = qs[l] - 1
+            b[k][0, l, :3] = qs[l] - 1
+    acc = H.rand_residues(rng, qs, (count,), N)
+    da, db, dacc = [dev(x) for x in a], [dev(x) for x in b], dev(acc)
+    out = tf.DeviceBuffer(count * L * N)
+    ctx.dot(None, [x.ptr for x in da], [x.ptr for x in db], out.ptr, count, L)
+    qv = np.array(qs, dtype=object)[None, :, None]
+    want = sum(x.astype(object) * y.astype(object) for x, y in zip(a, b)) % qv
+    assert np.array_equal(out.to_numpy((count, L, N)), want.astype(np.uint64))
+    ctx.dot(dacc.ptr, [x.ptr for x in da], [x.ptr for x in db], out.ptr, count, L)
+    assert np.array_equal(out.to_numpy((count, L, N)), ((want + acc.astype(object)) % qv).astype(np.uint64))
+    run = dev(acc)                                                 # the reference's loop: acc += a_k * b_k, one call per term
+    for k in range(min(terms, 6)):
+        ctx.mad(run.ptr, da[k].ptr, db[k].ptr, run.ptr, count, L)
+    ctx.dot(dacc.ptr, [x.ptr for x in da[:6]], [x.ptr for x in db[:6]], out.ptr, count, L)
+    assert np.array_equal(out.to_numpy((count, L, N)), run.to_numpy((count, L, N)))
+    idx = [L - 1, 0]                                               # limb subset, in the caller's order
+    sa = [dev(np.ascontiguousarray(x[:, idx])) for x in a[:3]]
+    sb = [dev(np.ascontiguousarray(x[:, idx])) for x in b[:3]]
+    o2 = tf.DeviceBuffer(count * 2 * N)
+    ctx.dot(None, [x.ptr for x in sa], [x.ptr for x in sb], o2.ptr, count, 2, idx)
+    w2 = (sum(x[:, idx].astype(object) * y[:, idx].astype(object) for x, y in zip(a[:3], b[:3])) % np.array([qs[i] for i in idx], dtype=object)[None, :, None])
+    assert np.array_equal(o2.to_numpy((count, 2, N)), w2.astype(np.uint64))
+    with pytest.raises(AssertionError):
+        ctx.dot(None, [], [], out.ptr, count, L)
+
+
 # ---------------------------------------------------------------------------------------------------
 # randomised shapes: degree, limb count, modulus sizes (mixed 30..61 bit), batch, level, special prime, component count
 # drawn from a seeded generator -- every operation of the path against the C oracle, bit for bit

@@ -242,6 +242,32 @@ def test_scheme_layer_on_a_callers_non_blocking_stream():
         R.ctx.set_stream(None)
 
 
+def test_dot_plain_equals_the_sum_of_plaintext_products():
+    """CipherText.dot_plain (tfhe_dot) against sum(c.mul_plain(p)) term by term: identical residues, and the decrypted slots."""
+    N = 1 << 11
+    R = tf.NegacyclicRing(N, chain(2**40 + 1, 4, N))
+    params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    rng = np.random.default_rng(31)
+    kp = tf.keygen(rng, params)
+    scale, K = 2**40, 5
+    vals = [np.repeat(((np.arange(1, N // 2 + 1) + 7 * k) / N).astype(complex)[None], 2, axis=0) for k in range(K)]
+    wts = [np.repeat(np.cos(np.arange(N // 2) * (k + 1) / 50.0).astype(complex)[None], 2, axis=0) for k in range(K)]
+    cts = [tf.encrypt(rng, kp, tf.ckks_encode(v, params.R_cipher(), scale), scale=scale) for v in vals]
+    pts = [tf.ckks_encode(w, params.R_cipher(), scale) for w in wts]
+    got = tf.CipherText.dot_plain(cts, pts)
+    want = None
+    for c, p in zip(cts, pts):
+        t = c.mul_plain(p)
+        want = t if want is None else want + t
+    assert got.scale == want.scale and len(got) == len(want)
+    for g, w in zip(got.cs, want.cs):
+        assert np.array_equal(g.to_numpy("dual"), w.to_numpy("dual"))
+    ref = sum(v * w for v, w in zip(vals, wts))
+    assert np.abs(tf.ckks_decode(tf.decrypt(kp, got), got.scale) - ref).max() < 1e-6
+    with pytest.raises(tf.UsageError):
+        tf.CipherText.dot_plain(cts, pts[:-1] + [tf.ckks_encode(wts[0], R, scale)])      # a plaintext of another ring
+
+
 def test_ckks_mul_rescale_pipeline():
     """the encrypted_mnist-style step: ct*ct -> relinearise (special prime) -> rescale."""
     N = 64

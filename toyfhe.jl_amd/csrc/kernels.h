@@ -1078,6 +1078,36 @@ __global__ __launch_bounds__(256) void k_pointwise(const u64* __restrict__ a, co
     }
 }
 
+// dst = (acc +) sum_k a_k .* b_k, limb-wise: the accumulation loop of the diagonal matrix-vector products (infer.jl:140-149:
+// `result += rotated * diagonal_k`, each a ring multiplication and a ring addition in the reference) as ONE pass over the
+// operands.  Exact: full 128-bit products are summed and reduced (Barrett) every `chunk` terms, chunk = 2^(62 - bits(q)) capped
+// at the term count -- the same canonical residues as the one-by-one mulmod / addmod sequence.
+#define TFHE_DOT_MAX 64
+struct dot_arg_t {
+    const u64* a[TFHE_DOT_MAX];
+    const u64* b[TFHE_DOT_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_dot(dot_arg_t D, const u64* __restrict__ acc, u64* __restrict__ dst,
+                                              const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 n) {
+    const u32 row = blockIdx.x, j = row % (u32)sel.n;
+    const ntt_limb_t L = LT[sel.idx[j]];
+    const size_t base = (size_t)row * n;
+    int bits = 0;
+    while ((L.q >> bits) != 0) bits++;
+    const int chunk = bits >= 62 ? 1 : (62 - bits >= 6 ? 64 : (1 << (62 - bits)));   // products summed between two reductions
+    for (u32 i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
+        u64 r = acc ? acc[base + i] : 0;
+        for (int k0 = 0; k0 < D.n; k0 += chunk) {
+            acc128 s{r, 0};
+            const int k1 = k0 + chunk < D.n ? k0 + chunk : D.n;
+            for (int k = k0; k < k1; k++) acc_mac(s, D.a[k][base + i], D.b[k][base + i]);
+            r = barrett_reduce128(s.lo, s.hi, L.br);
+        }
+        dst[base + i] = r;
+    }
+}
+
 // tensor (rlwe_she.jl:255-258) in the NTT domain: a,b [batch][2][limbs][N] -> out [batch][3][limbs][N]
 __global__ __launch_bounds__(256) void k_tensor(const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out,
                                                  const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 n) {

@@ -712,6 +712,29 @@ int tfhe_scalar_mul(tfhe_ctx* c, const uint64_t* scal, const uint64_t* a, uint64
     return run_pointwise<OP_SCAL>(c, a, nullptr, nullptr, d, n, l, idx, &sc);
 }
 
+int tfhe_dot(tfhe_ctx* c, const uint64_t* acc, const uint64_t* const* a, const uint64_t* const* b, int n_terms, uint64_t* dst,
+             int64_t count, int limbs, const int32_t* idx) {
+    if (!c || !a || !b || !dst) return fail(TFHE_E_BADARG, "null argument");
+    if (n_terms < 1) return fail(TFHE_E_BADARG, "tfhe_dot needs at least one term");
+    limb_sel_t sel;
+    int rc = make_sel(c, limbs, idx, &sel);
+    if (rc) return rc;
+    if (count < 0) return fail(TFHE_E_BADARG, "negative count");
+    if (count == 0) return TFHE_OK;
+    for (int k = 0; k < n_terms; k++)
+        if (!a[k] || !b[k]) return fail(TFHE_E_BADARG, "null operand %d", k);
+    const u64* running = acc;
+    for (int k0 = 0; k0 < n_terms; k0 += TFHE_DOT_MAX) {   // more than 64 terms: further launches accumulate onto dst
+        dot_arg_t D;
+        D.n = std::min(TFHE_DOT_MAX, n_terms - k0);
+        for (int k = 0; k < D.n; k++) { D.a[k] = a[k0 + k]; D.b[k] = b[k0 + k]; }
+        hipLaunchKernelGGL(k_dot, row_grid((unsigned)(count * limbs), (size_t)c->N), dim3(256), 0, c->stream, D, running, dst, c->limbs_dev, sel, (u32)c->N);
+        HIP_TRY(hipGetLastError());
+        running = dst;
+    }
+    return TFHE_OK;
+}
+
 int tfhe_tensor(tfhe_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, int64_t batch, int limbs, const int32_t* idx) {
     if (!c || !a || !b || !out) return fail(TFHE_E_BADARG, "null argument");
     limb_sel_t sel;

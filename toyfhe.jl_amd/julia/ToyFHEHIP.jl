@@ -155,6 +155,16 @@ function Base.broadcasted(::typeof(*), a::DevVec{T}, b::DevVec{T}) where {T<:CRT
                 modring(T, dst.n).handle, a.parent.ptr, b.parent.ptr, dst.ptr, 1, dst.limbs, C_NULL))
     OffsetArray(dst, axes(a)...)
 end
+# sum_k as[k] .* bs[k] in one device pass (tfhe_dot): the accumulation of the diagonal matrix-vector product, infer.jl:140-149
+function dot(as::Vector{<:DevVec{T}}, bs::Vector{<:DevVec{T}}) where {T<:CRTEncoded}
+    @assert length(as) == length(bs) && !isempty(as)
+    dst = HipVector{T}(as[1].parent.limbs, as[1].parent.n)
+    ap = Ptr{UInt64}[a.parent.ptr for a in as]
+    bp = Ptr{UInt64}[b.parent.ptr for b in bs]
+    check(ccall((:tfhe_dot, lib), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Ptr{Ptr{UInt64}}, Ptr{Ptr{UInt64}}, Cint, Ptr{UInt64}, Int64, Cint, Ptr{Int32}),
+                modring(T, dst.n).handle, C_NULL, ap, bp, length(as), dst.ptr, 1, dst.limbs, C_NULL))
+    OffsetArray(dst, axes(as[1])...)
+end
 function Base.broadcasted(::typeof(-), a::DevVec{T}) where {T<:CRTEncoded}
     dst = HipVector{T}(a.parent.limbs, a.parent.n)
     check(ccall((:tfhe_neg, lib), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Int64, Cint, Ptr{Int32}),

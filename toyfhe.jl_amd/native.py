@@ -111,6 +111,7 @@ def lib():
         "tfhe_neg": [vp, vp, vp, i64, i32, i32p],
         "tfhe_mul": [vp, vp, vp, vp, i64, i32, i32p],
         "tfhe_mad": [vp, vp, vp, vp, vp, i64, i32, i32p],
+        "tfhe_dot": [vp, vp, C.POINTER(vp), C.POINTER(vp), i32, vp, i64, i32, i32p],
         "tfhe_scalar_mul": [vp, u64p, vp, vp, i64, i32, i32p],
         "tfhe_tensor": [vp, vp, vp, vp, i64, i32, i32p],
         "tfhe_rescale": [vp, vp, vp, i64, i32, i32p],
@@ -152,7 +153,7 @@ EXPORTED_SYMBOLS = [
     "tfhe_last_error", "tfhe_device_count", "tfhe_set_device", "tfhe_ctx_create", "tfhe_ctx_destroy", "tfhe_ctx_psi",
     "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_wait_for", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
     "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_pack_poly", "tfhe_unpack_poly", "tfhe_broadcast_poly", "tfhe_alloc_stats", "tfhe_alloc_trim", "tfhe_comm_id", "tfhe_comm_create", "tfhe_comm_destroy", "tfhe_gather", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
-    "tfhe_mul", "tfhe_mad", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
+    "tfhe_mul", "tfhe_mad", "tfhe_dot", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
     "tfhe_keyswitch", "tfhe_rotate", "tfhe_rotate_many", "tfhe_galois_key_prepare", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
     "tfhe_bfv_plan_set_variant", "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
     "tfhe_event_create", "tfhe_event_destroy", "tfhe_event_record", "tfhe_event_elapsed_ms",
@@ -290,6 +291,15 @@ class Context:
 
     def mad(self, acc, a, b, dst, count, limbs, idx=None):
         check(lib().tfhe_mad(self.h, acc, a, b, dst, count, limbs, _idx(idx)))
+
+    def dot(self, acc, a_ptrs, b_ptrs, dst, count, limbs, idx=None):
+        """dst = (acc +) sum_k a_k .* b_k (tfhe_dot); a_ptrs / b_ptrs: equally long lists of device pointers"""
+        if len(a_ptrs) != len(b_ptrs):
+            raise AssertionError("tfhe_dot: as many a operands as b operands")
+        n = len(a_ptrs)
+        A = (C.c_void_p * n)(*a_ptrs)
+        B = (C.c_void_p * n)(*b_ptrs)
+        check(lib().tfhe_dot(self.h, acc, A, B, n, dst, count, limbs, _idx(idx)))
 
     def scalar_mul(self, scal, a, dst, count, limbs, idx=None):
         s = (C.c_uint64 * limbs)(*[int(x) for x in scal])

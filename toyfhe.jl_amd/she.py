@@ -382,6 +382,33 @@ class CipherText:
             cs = [c * re for c in self.cs]
         return CipherText(self.params, cs, Fraction(self.scale) ** 2)
 
+    @staticmethod
+    def dot_plain(cts, plains) -> "CipherText":
+        """sum_k cts[k] .* plains[k] for ciphertexts of one ring, length and scale and plaintexts already encoded at that scale
+        (ring elements): the accumulation loop of the diagonal matrix product (infer.jl:140-149) as one device pass per
+        component (tfhe_dot) instead of a ring multiplication and a ring addition per term; bit-identical to
+        `sum(c.mul_plain(p) for c, p in zip(cts, plains))`."""
+        cts, plains = list(cts), list(plains)
+        if not cts or len(cts) != len(plains):
+            raise AssertionError("dot_plain: as many ciphertexts as plaintexts, at least one")
+        c0 = cts[0]
+        c0._need_scale()
+        ring, n, batch = c0.ring(), c0[0].count, c0[0].batch
+        for c in cts:
+            if c.ring() != ring or len(c) != len(c0) or c.scale != c0.scale or c[0].count != n:
+                raise UsageError("dot_plain: ciphertexts of one ring, length, batch and scale")
+        for p in plains:
+            if not isinstance(p, RingElement) or p.ring != ring or p.count != n:
+                raise UsageError("dot_plain: plaintexts must be ring elements of the ciphertexts' ring and batch")
+        pb = [p.coeffs_dual() for p in plains]
+        out = []
+        for s_ in range(len(c0)):
+            ab = [c.cs[s_].coeffs_dual() for c in cts]
+            o = DeviceBuffer(n * ring.L * ring.N)
+            ring.ctx.dot(None, [x.ptr for x in ab], [x.ptr for x in pb], o.ptr, n, ring.L, ring.idx)
+            out.append(RingElement(ring, None, o, batch))
+        return CipherText(c0.params, out, Fraction(c0.scale) ** 2)
+
     def add_plain(self, x) -> "CipherText":
         """ct .+ float / ct .+ vector (:111-124): encoded at the ciphertext's scale and added to the first component."""
         self._need_scale()
