@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Key switches per second at N = 2^logN on a 6-limb + special-prime ring of 50-bit primes (the fused kernels at
+logN = 13 / 14).  usage: bench_ks_n.py <logN> <batch>   (TFHE_HIP_LIB=<other build> for A/B runs)"""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import toyfhe_jl_amd as tf
