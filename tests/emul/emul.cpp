@@ -184,7 +184,7 @@ int emul_bfv_fast(const uint64_t* qs, int ns, const uint64_t* pb, int nb, uint64
             u64* d = contract ? dst + p * ns * N + k : dst + p * nb * N + k;
 #define FAST_(S, P_)                                                                           \
     else if (ns == S && np == P_) {                                                            \
-        if (H->tab.narrow) { if (contract) bfv_contract_narrow<S, P_>(H->tab, s, N, d, N); else bfv_expand_narrow<S, P_>(H->tab, s, N, d, N); } \
+        if (H->tab.narrow) { u64 col[TFHE_FAST_MAX]; if (contract) bfv_contract_narrow<S, P_>(H->tab, s, N, d, N, col, 1); else bfv_expand_narrow<S, P_>(H->tab, s, N, d, N, col, 1); } \
         else { if (contract) bfv_contract_fast<S, P_, false>(H->tab, s, N, d, N); else bfv_expand_fast<S, P_, false>(H->tab, s, N, d, N); } \
     }
             if (false) {}

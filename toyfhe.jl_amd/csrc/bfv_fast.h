@@ -59,6 +59,44 @@ TFHE_HD u32 conv_alpha_exact(const u64 (&xi)[K], const u64* M, const u64* Aw, in
     return carries + (borrow ? 0u : 1u);
 }
 
+// The same decision with the K words read from a scratch column (col[j * stride]) by ROLLED loops: a handful of live
+// registers, whatever K is.  The narrow bodies take this form -- inlined and unrolled, the rare path tripled the register
+// allocation of the whole kernel (66 -> 124 VGPRs in the contraction), which is the allocation every wave pays for.
+TFHE_HD u32 conv_alpha_exact_col(int K, const u64* col, int stride, const u64* M, const u64* Aw, int nwords, u32 carries) {
+    const u64 mult = (u64)carries + 1;
+    u64 acc_lo = 0, acc_hi = 0, acc_ex = 0, mcarry = 0, borrow = 0;
+#pragma unroll 1
+    for (int w = 0; w <= nwords; w++) {
+        if (w < nwords) {
+#pragma unroll 1
+            for (int j = 0; j < K; j++) {
+                const u64 x = col[(size_t)j * stride], mw = M[(size_t)j * nwords + w];
+                u64 lo, hi;
+                mul64_full(x, mw, lo, hi);
+                u64 s = acc_lo + lo;
+                const u64 c = (s < lo);
+                acc_lo = s;
+                s = acc_hi + hi;
+                u64 c2 = (s < hi);
+                s += c;
+                c2 += (s < c);
+                acc_hi = s;
+                acc_ex += c2;
+            }
+        }
+        const u64 xw = acc_lo;
+        acc_lo = acc_hi; acc_hi = acc_ex; acc_ex = 0;
+        const u64 aw = w < nwords ? Aw[w] : 0;
+        u64 plo, phi;
+        mul64_full(aw, mult, plo, phi);
+        const u64 yw = plo + mcarry;
+        mcarry = phi + (yw < plo);
+        const u64 d = xw - yw;
+        borrow = (u64)(xw < yw) | (u64)(d < borrow);
+    }
+    return carries + (borrow ? 0u : 1u);
+}
+
 #define TFHE_FAST_MAX 12  // max NS / NP of the fast path tables
 
 struct bfv_fast_tab_t {
@@ -102,6 +140,14 @@ struct bfv_fast_tab_t {
     u64 n_cNegA2[TFHE_FAST_MAX];                // -(P mod q_i)                 (times alpha_2)
     u64 n_cNegHalf[TFHE_FAST_MAX];              // -(floor(P/2) mod q_i)        (plain)
     // exact-integer fp64 parts of the narrow path (every modulus below TFHE_FP_QMAX, fp64arith.h)
+    mont26_t mq[TFHE_FAST_MAX], mp[TFHE_FAST_MAX];      // radix-2^26 Montgomery constants of q_i / p_j (acc52_redc); the n_* constants
+                                                        // above carry the factor 2^78 of that reduction
+    u64 n_cB2[TFHE_FAST_MAX];                           // c_b2 2^78 mod p_j            (plain, added once)
+    // output-major rows of the three matrices (the constants of ONE output contiguous: one or two wide scalar loads per output,
+    // six accumulator registers live at a time)
+    u64 t_eC[TFHE_FAST_MAX][TFHE_FAST_MAX];             // [j][i] = n_eC[i][j]
+    u64 t_cNegC1[TFHE_FAST_MAX][TFHE_FAST_MAX];         // [j][i] = n_cNegC1[i][j]
+    u64 t_cC2[TFHE_FAST_MAX][TFHE_FAST_MAX];            // [i][j] = n_cC2[j][i]
     double f_q[TFHE_FAST_MAX], f_qinv[TFHE_FAST_MAX];   // q_i, 1/q_i
     double f_p[TFHE_FAST_MAX], f_pinv[TFHE_FAST_MAX];   // p_j, 1/p_j
     double f_ea[TFHE_FAST_MAX], f_eb[TFHE_FAST_MAX];    // expand:   xi_i = x_i ea_i + eb_i mod q_i  (ea = (q/q_i)^-1, eb = floor(q/2) ea)
@@ -213,41 +259,72 @@ TFHE_HD double fp_affine(u64 x, double a, double b, double p, double pinv) {
 // alpha = floor(Σ xi_j / a_j) from a double sum: |S' - S| < K^2 2^-52 <= 2^-44 for K <= 16, so the floor is certain
 // unless the fraction is within 2^-40 of an integer -- then the exact multi-word comparison decides between the two
 // candidates.  (All three conversions are offset by floor(A/2), so that only happens for values near +-A/2.)
+// a 26-bit-split operand of the carry-free product sums, split ONCE where it is produced (left to itself the compiler re-derives
+// the halves of a 64-bit word per use and drags the word's upper bits through every product: 324 v_mov_b32 and 148 spare
+// v_mad_u64_u32 in the contraction's second conversion)
+struct split26 {
+    u32 lo, hi;
+};
+TFHE_HD split26 split_of(u64 x) {
+    split26 r{(u32)x & 0x3ffffffu, (u32)(x >> 26)};
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(r.lo), "+v"(r.hi));  // opaque (NOT volatile: a volatile asm orders every load around it and serialises the kernel): the halves are what the products see, not the 64-bit word
+#endif
+    return r;
+}
+TFHE_HD u64 join_of(split26 x) { return ((u64)x.hi << 26) | x.lo; }
+TFHE_HD void acc52_macs(acc52& a, split26 x, u64 cpacked) { acc52_mac(a, x.lo, x.hi, (u32)cpacked, (u32)(cpacked >> 32)); }
+// small multiplier (the alpha counts, < 2^26): two partial products
+TFHE_HD void acc52_mac_small(acc52& a, u32 x, u64 cpacked) {
+    a.s0 += (u64)x * (u32)cpacked;
+    a.s1 += (u64)x * (u32)(cpacked >> 32);
+}
+
+// alpha = floor(Σ xi_j / a_j) from a double sum: |S' - S| < K^2 2^-52 <= 2^-44 for K <= 16, so the floor is certain
+// unless the fraction is within 2^-40 of an integer -- then the exact multi-word comparison decides between the two
+// candidates.  (All three conversions are offset by floor(A/2), so that only happens for values near +-A/2.)
 template <int K>
-TFHE_HD u32 conv_alpha_fp(const double (&xd)[K], const u64 (&xi)[K], const double* ainv, const u64* M, const u64* Aw, int nwords) {
+TFHE_HD u32 conv_alpha_fp(const double (&xd)[K], const split26 (&xs)[K], const double* ainv, const u64* M, const u64* Aw, int nwords,
+                          u64* col, int cstride) {
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < K; j++) s = fp_fma(xd[j], ainv[j], s);
     const double fl = __builtin_floor(s), f = s - fl;
-    const u32 n = (u32)fl;
-    if (f > 0x1p-40 && f < 1.0 - 0x1p-40) return n;
-    if (f <= 0x1p-40) return n == 0 ? 0u : conv_alpha_exact<K>(xi, M, Aw, nwords, n - 1);
-    return conv_alpha_exact<K>(xi, M, Aw, nwords, n);
+    u32 n = (u32)fl;
+    if (!(f > 0x1p-40 && f < 1.0 - 0x1p-40)) {  // rare: the words go through the scratch column to the rolled exact decision
+#pragma unroll
+        for (int j = 0; j < K; j++) col[(size_t)j * cstride] = join_of(xs[j]);
+        if (f <= 0x1p-40) n = n == 0 ? 0u : conv_alpha_exact_col(K, col, cstride, M, Aw, nwords, n - 1);
+        else n = conv_alpha_exact_col(K, col, cstride, M, Aw, nwords, n);
+    }
+    return n;
 }
 
 template <int NS, int NP>
-TFHE_HD void bfv_expand_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld, bool copy_shared = true) {
+TFHE_HD void bfv_expand_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld, u64* col, int cstride,
+                               bool copy_shared = true) {
     static_assert(NS + 2 <= 16 && NP + 2 <= 16, "acc52 term budget");
-    u64 x[NS], xi[NS];
+    u64 x[NS];
+    split26 xs[NS];
     double xd[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) {
         x[i] = src[(size_t)i * ls];
         xd[i] = fp_affine(x[i], B.f_ea[i], B.f_eb[i], B.f_q[i], B.f_qinv[i]);
-        xi[i] = fp_to_u64(xd[i]);
+        xs[i] = split_of(fp_to_u64(xd[i]));
     }
-    const u32 alpha = conv_alpha_fp<NS>(xd, xi, B.f_qinv, B.Mq, B.Aq, B.nwq);
+    const u32 alpha = conv_alpha_fp<NS>(xd, xs, B.f_qinv, B.Mq, B.Aq, B.nwq, col, cstride);
     if (copy_shared) {
 #pragma unroll
         for (int i = 0; i < NS; i++) dst[(size_t)B.pos_s[i] * ld] = x[i];
     }
 #pragma unroll
-    for (int j = 0; j < NP; j++) {
+    for (int j = 0; j < NP; j++) {  // output-major: the constants of output j are one contiguous row
         acc52 a{B.n_eNegHalf[j], 0, 0};
 #pragma unroll
-        for (int i = 0; i < NS; i++) acc52_macp(a, xi[i], B.n_eC[i][j]);
-        acc52_macp(a, (u64)alpha, B.n_eNegA[j]);
-        dst[(size_t)B.pos_p[j] * ld] = acc52_reduce(a, B.pb[j]);
+        for (int i = 0; i < NS; i++) acc52_macs(a, xs[i], B.t_eC[j][i]);
+        acc52_mac_small(a, alpha, B.n_eNegA[j]);
+        dst[(size_t)B.pos_p[j] * ld] = acc52_redc(a, B.mp[j]);
     }
 }
 
@@ -267,35 +344,38 @@ TFHE_HD u64 centred_double_bits(u64 r, u64 q) {
 // switch lifts its digit rows into (rlwe_she.jl:326-329); used for the c2 polynomial of a multiplication that is
 // relinearised next (internal buffer of tfhe_bfv_mul_relin only)
 template <int NS, int NP>
-TFHE_HD void bfv_contract_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld, bool lifted_out = false) {
-    u64 xi[NS];
+TFHE_HD void bfv_contract_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld, u64* col, int cstride,
+                                 bool lifted_out = false) {
+    split26 xs[NS];
     double xd[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) {  // ξ_i of r = (t y + h) mod q
         xd[i] = fp_affine(src[(size_t)B.pos_s[i] * ls], B.f_ca[i], B.f_cb[i], B.f_q[i], B.f_qinv[i]);
-        xi[i] = fp_to_u64(xd[i]);
+        xs[i] = split_of(fp_to_u64(xd[i]));
     }
-    const u32 a1 = conv_alpha_fp<NS>(xd, xi, B.f_qinv, B.Mq, B.Aq, B.nwq);
-    u64 xp[NP];
+    const u32 a1 = conv_alpha_fp<NS>(xd, xs, B.f_qinv, B.Mq, B.Aq, B.nwq, col, cstride);
+    split26 xps[NP];
     double xpd[NP];
+    // ξ'_j of w + floor(P/2) in basis P: one product-sum and one reduction per limb, output-major
 #pragma unroll
-    for (int j = 0; j < NP; j++) {  // ξ'_j of w + floor(P/2) in basis P: one product-sum, one reduction
-        acc52 a{B.c_b2[j], 0, 0};
-        acc52_macp(a, src[(size_t)B.pos_p[j] * ls], B.n_cA2[j]);
+    for (int j = 0; j < NP; j++) {
+        acc52 a{B.n_cB2[j], 0, 0};
+        acc52_macs(a, split_of(src[(size_t)B.pos_p[j] * ls]), B.n_cA2[j]);
 #pragma unroll
-        for (int i = 0; i < NS; i++) acc52_macp(a, xi[i], B.n_cNegC1[i][j]);
-        acc52_macp(a, (u64)a1, B.n_cA1[j]);
-        xp[j] = acc52_reduce(a, B.pb[j]);
-        xpd[j] = fp_from_u64(xp[j]);
+        for (int i = 0; i < NS; i++) acc52_macs(a, xs[i], B.t_cNegC1[j][i]);
+        acc52_mac_small(a, a1, B.n_cA1[j]);
+        const u64 xpj = acc52_redc(a, B.mp[j]);
+        xps[j] = split_of(xpj);
+        xpd[j] = fp_from_u64(xpj);
     }
-    const u32 a2 = conv_alpha_fp<NP>(xpd, xp, B.f_pinv, B.Mp, B.Ap, B.nwp);
+    const u32 a2 = conv_alpha_fp<NP>(xpd, xps, B.f_pinv, B.Mp, B.Ap, B.nwp, col, cstride);
 #pragma unroll
     for (int i = 0; i < NS; i++) {
         acc52 a{B.n_cNegHalf[i], 0, 0};
 #pragma unroll
-        for (int j = 0; j < NP; j++) acc52_macp(a, xp[j], B.n_cC2[j][i]);
-        acc52_macp(a, (u64)a2, B.n_cNegA2[i]);
-        const u64 r = acc52_reduce(a, B.qb[i]);
-        dst[(size_t)i * ld] = lifted_out ? centred_double_bits(r, B.qb[i].q) : r;
+        for (int j = 0; j < NP; j++) acc52_macs(a, xps[j], B.t_cC2[i][j]);
+        acc52_mac_small(a, a2, B.n_cNegA2[i]);
+        const u64 r = acc52_redc(a, B.mq[i]);
+        dst[(size_t)i * ld] = lifted_out ? centred_double_bits(r, join_of(split26{B.mq[i].pl, B.mq[i].ph})) : r;
     }
 }

@@ -196,22 +196,39 @@ inline bool build_bfv_fast_host(const std::vector<u64>& qs, const std::vector<u6
             B.f_ca[i] = (double)B.c_a1[i].w; B.f_cb[i] = (double)B.c_b1[i];
         }
         for (int j = 0; j < np; j++) { B.f_p[j] = (double)P[j]; B.f_pinv[j] = 1.0 / (double)P[j]; }
+        // every constant operand of a product sum carries the factor R = 2^78 that acc52_redc divides out
         auto neg = [](u64 c, u64 m) { return c ? m - c : 0; };
+        auto mont = [](u64 m) {
+            mont26_t M;
+            M.pl = (u32)(m & 0x3ffffffu);
+            M.ph = (u32)(m >> 26);
+            u32 inv = 1;  // m^-1 mod 2^26 by Newton iteration (m odd)
+            for (int it = 0; it < 5; it++) inv *= 2u - (u32)m * inv;
+            M.pp = (0u - inv) & 0x3ffffffu;
+            M.pad_ = 0;
+            return M;
+        };
+        auto fold = [](u64 c, u64 m) { return mulmod_slow(c, powmod(2, TFHE_MONT26_RBITS, m), m); };
         for (int j = 0; j < np; j++) {
             const u64 pj = P[j];
-            B.n_eNegA[j] = pack26(neg(B.e_A[j], pj));
-            B.n_eNegHalf[j] = neg(B.e_halfT[j], pj);
-            B.n_cA2[j] = pack26(B.c_a2[j].w);
-            B.n_cA1[j] = pack26(B.c_A1[j]);
+            B.mp[j] = mont(pj);
+            B.n_eNegA[j] = pack26(fold(neg(B.e_A[j], pj), pj));
+            B.n_eNegHalf[j] = fold(neg(B.e_halfT[j], pj), pj);
+            B.n_cA2[j] = pack26(fold(B.c_a2[j].w, pj));
+            B.n_cA1[j] = pack26(fold(B.c_A1[j], pj));
+            B.n_cB2[j] = fold(B.c_b2[j], pj);
             for (int i = 0; i < ns; i++) {
-                B.n_eC[i][j] = pack26(B.e_C[i][j]);
-                B.n_cNegC1[i][j] = pack26(neg(B.c_C1[i][j], pj));
-                B.n_cC2[j][i] = pack26(B.c_C2[j][i]);
+                B.n_eC[i][j] = pack26(fold(B.e_C[i][j], pj));
+                B.n_cNegC1[i][j] = pack26(fold(neg(B.c_C1[i][j], pj), pj));
+                B.n_cC2[j][i] = pack26(fold(B.c_C2[j][i], qs[i]));
             }
         }
+        for (int i = 0; i < ns; i++)
+            for (int j = 0; j < np; j++) { B.t_eC[j][i] = B.n_eC[i][j]; B.t_cNegC1[j][i] = B.n_cNegC1[i][j]; B.t_cC2[i][j] = B.n_cC2[j][i]; }
         for (int i = 0; i < ns; i++) {
-            B.n_cNegA2[i] = pack26(neg(B.c_A2[i], qs[i]));
-            B.n_cNegHalf[i] = neg(B.c_halfT[i], qs[i]);
+            B.mq[i] = mont(qs[i]);
+            B.n_cNegA2[i] = pack26(fold(neg(B.c_A2[i], qs[i]), qs[i]));
+            B.n_cNegHalf[i] = fold(neg(B.c_halfT[i], qs[i]), qs[i]);
         }
     }
     B.lazy_q = lazy_of(maxq, ns);

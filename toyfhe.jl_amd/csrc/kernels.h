@@ -1948,7 +1948,10 @@ __global__ __launch_bounds__(256) void k_bfv_expand_fast(const u64* __restrict__
     const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
     const size_t p = blockIdx.x / gx;
     if (k >= n) return;
-    if constexpr (NARROW) bfv_expand_narrow<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
+    if constexpr (NARROW) {
+        __shared__ u64 col[(NS > NP ? NS : NP) * 256];  // scratch column of the rare exact-alpha decision (bfv_fast.h conv_alpha_fp)
+        bfv_expand_narrow<NS, NP>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, col + threadIdx.x, 256, copy_shared != 0);
+    }
     else bfv_expand_fast<NS, NP, false>(*Bt, src + p * NS * n + k, n, dst + p * (NS + NP) * n + k, n, copy_shared != 0);
 }
 // LIFT3 (narrow bodies, products: three polynomials per ciphertext): every third polynomial (c2) leaves as centred doubles
@@ -1961,7 +1964,8 @@ __global__ __launch_bounds__(256) void k_bfv_contract_fast(const u64* __restrict
     const size_t p = b;
     if (k >= n) return;
     if constexpr (NARROW) {
-        bfv_contract_narrow<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n, LIFT3 && b % 3u == 2u);
+        __shared__ u64 col[(NS > NP ? NS : NP) * 256];  // scratch column of the rare exact-alpha decision (bfv_fast.h conv_alpha_fp)
+        bfv_contract_narrow<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n, col + threadIdx.x, 256, LIFT3 && b % 3u == 2u);
     } else {
         bfv_contract_fast<NS, NP, false>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
     }

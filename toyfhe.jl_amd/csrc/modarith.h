@@ -119,6 +119,37 @@ TFHE_HD void acc52_fold(const acc52& a, u64& lo, u64& hi) {
     hi = h;
 }
 
+// Montgomery reduction of a carry-free product sum in radix 2^26: z = s0 + s1 2^26 + s2 2^52 (s0, s1 < 2^58 and s2 < 2^53, which the
+// 16-term budget of acc52 guarantees for operands below 2^50 + 2^40) -> z 2^-78 mod p, canonical.  Three rounds, each clearing the
+// low 26 bits of the lowest live lane with a multiple of p = ph 2^26 + pl and carrying the rest (which fits 32 bits) upwards:
+// mul_lo, two v_mad_u64_u32, one funnel shift and one 64-bit add per round -- about 20 instructions all in, against
+// ~50 for acc52_fold + barrett_reduce128.  The factor 2^78 is folded into the constant operands of the sum on the host
+// (bfv_tables.h mont26_fold), so the result is the plain residue.
+struct mont26_t {
+    u32 pl, ph;  // p = ph 2^26 + pl
+    u32 pp;      // -p^-1 mod 2^26
+    u32 pad_;
+};
+#define TFHE_MONT26_RBITS 78
+TFHE_HD u64 acc52_redc(acc52 a, const mont26_t& M) {
+    // rounds one and two take the multiplier unmasked (any m = -s p^-1 mod 2^26 clears the low 26 bits; a 32-bit m only makes
+    // the carries larger: s1 < 2^57.1, s2 < 2^56.1, both carries still fit 32 bits); the last round masks, so that r < 2 p
+    u32 m = (u32)a.s0 * M.pp;
+    a.s0 += (u64)m * M.pl;  // low 26 bits are zero now
+    a.s1 += (u64)m * M.ph;
+    a.s1 += (u64)(u32)(a.s0 >> 26);
+    m = (u32)a.s1 * M.pp;
+    a.s1 += (u64)m * M.pl;
+    a.s2 += (u64)m * M.ph;
+    a.s2 += (u64)(u32)(a.s1 >> 26);
+    m = ((u32)a.s2 * M.pp) & 0x3ffffffu;
+    a.s2 += (u64)m * M.pl;
+    const u64 r = (u64)m * M.ph + (u64)(u32)(a.s2 >> 26);  // < p + 2^31 < 2 p
+    const u64 p = ((u64)M.ph << 26) | M.pl;
+    unsigned long long d;
+    return __builtin_usubll_overflow(r, p, &d) ? r : (u64)d;  // the borrow of r - p selects
+}
+
 // bit reversal of the low `bits` bits
 TFHE_HD u32 brev_bits(u32 x, int bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
