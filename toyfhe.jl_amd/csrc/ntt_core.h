@@ -562,11 +562,34 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
     constexpr bool TO_GLOBAL = (S0 == 0);
     u64 o[TO_GLOBAL ? G::E : 1];
     if (TO_GLOBAL) {
+        // The addend words are requested as ONE block before the results are canonicalised (that arithmetic covers part of
+        // their latency).  Left inside the store loop behind `if (addend)`, each of the 2^(LOGB-LOGT) loads was issued and
+        // awaited on its own (s_waitcnt vmcnt(0), which also drains the previous store): 32 serial round trips per inverse
+        // transform of the fused key switch -- about a fifth of that kernel's time.
+        u64 add[G::E];
+        if (addend) {
+#pragma unroll
+            for (int u = 0; u < G::SETS; u++) {
+                if (USEL >= 0 && u != USEL) continue;
+                u32 c0, hi, base;
+                G::template coords<FROM_GLOBAL>(tid, u, c0, hi, base);
+#pragma unroll
+                for (int r = 0; r < G::R; r++) add[u * G::R + r] = addend[base + ((u32)r << G::LO)];
+            }
+            TFHE_SCHED_FENCE();
+        }
         // finish every result before the store phase starts (otherwise the scheduler interleaves the two
         // and the register allocator spills)
 #pragma unroll
         for (int i = 0; i < G::E; i++) o[i] = SCALE ? A::out_inv_scaled(v[i], C) : A::out_inv_lazy(v[i], C);
         TFHE_SCHED_FENCE();
+        if (addend) {
+#pragma unroll
+            for (int i = 0; i < G::E; i++) {
+                if (USEL >= 0 && i / G::R != USEL) continue;
+                o[i] = addmod(o[i], add[i], C.q);
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
@@ -577,9 +600,7 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
         for (int r = 0; r < G::R; r++) {
             const u32 j = base + ((u32)r << G::LO);
             if (TO_GLOBAL) {
-                u64 w = o[u * G::R + r];
-                if (addend) w = addmod(w, addend[j], C.q);
-                gdst[j] = w;
+                gdst[j] = o[u * G::R + r];
             } else {
                 typename A::elem e = v[u * G::R + r];
                 A::range_inv(e, C);
