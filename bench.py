@@ -12,9 +12,14 @@ with N ranks (RCCL); under torchrun the environment's WORLD_SIZE is what runs an
 timed region the optional final gather (north_star: "RCCL over xGMI only for the final gather") is timed on its own, so
 the JSON carries the rate without (`value`) and with it (`gather.value_with_gather`).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu] [--no-ntt] [--no-gather]
+After the headline line's legs, rank 0 of a single-GPU run also measures the other BASELINE.json configurations
+(`other_configs`: cfg#3 / #4 / #5 key switch, rotation and rescale rates, N = 2^16 and 60-bit NTT rates, each case checked
+against the oracle on one ciphertext before it is timed -- tools/bench_configs.py); `--no-configs` skips that leg.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu] [--no-ntt] [--no-gather] [--no-configs]
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -42,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ntt", action="store_true", help="skip the stand-alone NTT record")
     ap.add_argument("--no-gather", action="store_true", help="skip the timed final gather (multi-rank runs)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations (other_configs leg)")
+    ap.add_argument("--configs-scale", type=int, default=1, help="divide the batches of the other_configs cases by this")
     ap.add_argument("--cpu-sample", type=int, default=0, help="ciphertext pairs in the all-core CPU sample (0 = auto)")
     ap.add_argument("--cabi-gather", action="store_true",
                     help="time the final gather through the C ABI (tfhe_gather, the library's own RCCL communicator) instead of torch.distributed")
@@ -79,6 +86,17 @@ def load_pmc():
         return json.load(open(PMC_FILE))
     except Exception:
         return None
+
+
+def source_id():
+    """sha256 over the engine's sources (csrc/* and the header): what the library running here was built from.  The PMC file
+    carries the same id of the build it profiled (tools/pmc_bench.py); a mismatch means its counters describe other kernels."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "toyfhe.jl_amd", "csrc")
+    for f in sorted(os.listdir(src)) + [os.path.join("..", "..", "include", "toyfhe_hip.h")]:
+        h.update(f.encode())
+        h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -142,12 +160,18 @@ def main():
     ctx.prof_enable(True)
     tdist.barrier()
     torch.cuda.synchronize()
+    evs = [tf.Event() for _ in range(args.steps + 1)]                 # per-step device time (median of >= 5)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        evs[k].record(ctx)
         step()
+    evs[args.steps].record(ctx)
     torch.cuda.synchronize()
     tdist.barrier()
     t1 = time.perf_counter()
+    step_ms = sorted(evs[k].elapsed_ms(evs[k + 1]) for k in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    median_ms = tdist.max_over_ranks(median_ms, device=coll_dev)
     launches, limb_polys, ntt_ms = ctx.prof_read()
     ctx.prof_enable(False)
     elapsed = tdist.max_over_ranks(t1 - t0, device=coll_dev)
@@ -201,7 +225,9 @@ def main():
     pmc = load_pmc()
     valu_gips = valu_frac = hbm_frac = traffic = clock_ghz = valu_frac_clk = None
     sq = {}
-    if pmc and launches:
+    src_id = source_id()
+    pmc_stale = bool(pmc) and pmc.get("source_id") != src_id           # counters of another build: not scaled onto this run
+    if pmc and launches and not pmc_stale:
         fused = {k: v for k, v in pmc["kernels"].items() if "k_bfv_core_fused" in k or "k_ks_fused" in k}
         cts = B * args.steps                                          # ciphertext-muls carried by this rank's launches
         per_ct = lambda key: sum(v.get(key, 0.0) / v["launches"] for v in fused.values()) / pmc["batch"]
@@ -242,6 +268,7 @@ def main():
         "ntt_share_of_step": ntt_s / (t1 - t0) if t1 > t0 else None,
         "counters": sq or None,
         "pmc_source": (pmc or {}).get("note"),
+        "pmc_stale": pmc_stale, "source_id": src_id, "pmc_source_id": (pmc or {}).get("source_id"),
     }
 
     result = {
@@ -252,6 +279,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_median": median_ms, "value_at_median_step": B * world / (median_ms * 1e-3),
+        "nranks_seen": tdist.world_size_seen(),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -320,7 +349,14 @@ def main():
                                             f"(exact BigInt-style conversions, radix-2 NTT), OpenMP over the batch, {t_all:.1f} s",
                                   "single_thread": {"value": n1 / t_one, "cores": 1,
                                                     "sample": f"{n1} ciphertext pairs, 1 thread (the reference is single-threaded), {t_one:.1f} s"}}
-    for enabled, leg in ((rank == 0 and not args.no_ntt, ntt_record), (rank == 0 and world == 1 and not args.no_cpu, cpu_record)):
+    # ---- the other BASELINE.json configurations (secondary rates; every case oracle-checked before it is timed) -----------
+    def configs_record():
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs                                        # imports oracle.ref_cpu as the checker of each case
+        result["other_configs"] = bench_configs.run(args.configs_scale)
+
+    for enabled, leg in ((rank == 0 and not args.no_ntt, ntt_record), (rank == 0 and world == 1 and not args.no_cpu, cpu_record),
+                         (rank == 0 and world == 1 and not args.no_configs, configs_record)):
         if enabled:
             try:                                                        # a failing side record must not cost the headline line
                 leg()

@@ -165,13 +165,17 @@ int tfhe_galois_key_prepare(tfhe_ctx *ctx, int key_limbs, int n_digits, uint64_t
 
 /* ---- K14: keyswitch with base-2^w digits (relin_window = w != 0, rlwe_she.jl:330-338; the default for
  * single-modulus rings, rlwe_she.jl:271) -------------------------------------------------------------
- * The ring is limbs 0..level-1 of ctx (no special prime).  Digit i of a coefficient is digit i of
- * convert(Integer, x) in [0, Q) -- reconstructed exactly from the residues when level > 1 -- embedded in every
- * limb; out_s = c_s + sum_i key_i,s * digit_i.
- *   evk: [n_windows][2][level][N], component 0 = mask, 1 = masked, NTT domain; n_windows must equal
- *        ndigits(Q, base = 2^w) = ceil(bitlength(Q) / w) (rlwe_she.jl:282,333), else TFHE_E_PARAMS_MISMATCH.
+ * The ciphertext ring is limbs 0..level-1 of ctx, the key ring limbs 0..key_limbs-1 (as tfhe_keyswitch).  Digit i of a
+ * coefficient is digit i of convert(Integer, x) in [0, Q_level) -- reconstructed exactly from the residues when
+ * level > 1 -- embedded in every working limb; out_s = c_s + sum_i key_i,s * digit_i.
+ *   special != 0: ModulusRaised (modulusraising.jl:35-49) -- limb key_limbs-1 is the special prime P, the working limbs
+ *        are [0..level-1, key_limbs-1], c is raised to P c and the sums are contracted by floor(./P) (crt.jl:215-220).
+ *   evk: [n_windows][2][key_limbs][N], component 0 = mask, 1 = masked, NTT domain; n_windows >= ndigits(Q_level, base = 2^w)
+ *        = ceil(bitlength(Q_level) / w) (rlwe_she.jl:282,333; a key of a larger ring has more components, the first
+ *        ndigits(Q_level) are used, rlwe_she.jl:340), else TFHE_E_PARAMS_MISMATCH.
  *   window_bits: 1..32 with 2^w below every modulus.   ct / out as tfhe_keyswitch. */
-int tfhe_keyswitch_window(tfhe_ctx *ctx, int level, int window_bits, const uint64_t *evk, int n_windows, const uint64_t *ct, int polys, uint64_t *out, int64_t batch);
+int tfhe_keyswitch_window(tfhe_ctx *ctx, int key_limbs, int level, int special, int window_bits, const uint64_t *evk, int n_windows,
+                          const uint64_t *ct, int polys, uint64_t *out, int64_t batch);
 
 /* ---- CKKS encode / decode (float; ckksencoding.jl:56-97, FixedRational ckks.jl:35-59) -- SURVEY §8(f) ----
  * The ring is limbs 0..level-1 of ctx.  scale = scale_mant * 2^scale_exp2 (2^40 = (1, 40); any positive scale to

@@ -453,13 +453,15 @@ def rns_digits(c_end, ring: Ring, target: Ring):
     return ps
 
 
-def window_digits(c_end, ring: Ring, w: int):
-    """rlwe_she.jl:330-338: base-2^w digits of the unsigned integer representative."""
+def window_digits(c_end, ring: Ring, w: int, target: Ring = None):
+    """rlwe_she.jl:330-338: base-2^w digits of the unsigned integer representative of c[end] in ℛ = ring(c.cs[1]) (:333:
+    nwindows = ndigits(modulus(coefftype(ℛ))), the CIPHERTEXT ring), each digit polynomial an element of typeof(c1) (:336):
+    with ModulusRaised that is the expanded ring [q_1..q_l, P] (modulusraising.jl:35-41) -- ``target``."""
     nwin = ndigits(ring.Q, 2 ** w)
     ints = poly_to_ints(c_end, ring)
     ps = []
     for i in range(nwin):
-        ps.append(poly_from_ints([(x >> (i * w)) & ((1 << w) - 1) for x in ints], ring))
+        ps.append(poly_from_ints([(x >> (i * w)) & ((1 << w) - 1) for x in ints], target or ring))
     return ps
 
 
@@ -504,8 +506,7 @@ def keyswitch(evk, ct, cring: Ring, keyring: Ring, special: bool, relin_window: 
     if relin_window == 0:
         ps = rns_digits(ct[-1], cring, wring)
     else:
-        assert not special
-        ps = window_digits(ct[-1], cring, relin_window)
+        ps = window_digits(ct[-1], cring, relin_window, wring)   # the first len(ps) key components are used (rlwe_she.jl:340)
     for i, p in enumerate(ps):
         mask = [evk[i][0][j] for j in which]      # downswitch_keyelement, crt.jl:238-244 /
         masked = [evk[i][1][j] for j in which]    # modulusraising.jl:43-49

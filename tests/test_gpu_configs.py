@@ -289,3 +289,79 @@ def test_cfg5_ckks_mnist_ring_decrypt_level():
     r = tf.rotate(gk, sq)
     got = tf.ckks_decode(tf.decrypt(kp, r), r.scale)
     assert np.abs(got - np.roll(x * x, 1)).max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole-batch cross-checks (an item-walk bug at ciphertext 300 of a sub-block walk must not pass): the
+# one-operation-per-launch path (NTT variant 3) against the default fused / sub-block path on EVERY ciphertext, plus the
+# batch-permutation property
+# ---------------------------------------------------------------------------------------------------
+def _whole_batch_keyswitch_crosscheck(N, qs, L, batch, seed, g):
+    Lk = len(qs)
+    ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(seed)
+    devk = dev(H.uniform_evk(rng, qs, Lk, N))
+    ct = device_uniform(ctx, L, batch * 2, seed)
+    n = batch * 2 * L * N
+    out, out3 = tf.DeviceBuffer(n), tf.DeviceBuffer(n)
+    ctx.rotate(Lk, L, True, devk.ptr, Lk, g, ct.ptr, out.ptr, batch)
+    ctx.set_ntt_variant(3)
+    ctx.rotate(Lk, L, True, devk.ptr, Lk, g, ct.ptr, out3.ptr, batch)
+    ctx.set_ntt_variant(0)
+    a = out.to_numpy((batch, 2, L, N))
+    assert np.array_equal(out3.to_numpy((batch, 2, L, N)), a)
+    del out3
+    # batch independence: the permuted batch gives the permuted result
+    perm = rng.permutation(batch)
+    ctp = dev(ct.to_numpy((batch, 2, L, N))[perm])
+    ctx.rotate(Lk, L, True, devk.ptr, Lk, g, ctp.ptr, out.ptr, batch)
+    assert np.array_equal(out.to_numpy((batch, 2, L, N)), a[perm])
+    # rescale of the permuted batch: the oracle on ciphertexts spread over the whole batch (crt.jl:215-220, unsigned c_last)
+    res = tf.DeviceBuffer(batch * 2 * (L - 1) * N)
+    ctx.rescale(out.ptr, res.ptr, batch * 2, L)
+    ref = ref_cpu.RefCtx(N, qs)
+    picks = sorted({0, batch // 3, (2 * batch) // 3 + 1, batch - 1})
+    want = ref.modswitch(a[perm][picks].reshape(-1, L, N), idx=range(L)).reshape(len(picks), 2, L - 1, N)
+    assert np.array_equal(fetch(res, (batch, 2, L - 1, N), picks), want)
+
+
+def test_cfg3_whole_batch_crosscheck_and_permutation():
+    N = 1 << 15
+    _whole_batch_keyswitch_crosscheck(N, chain(2**40 + 1, 11, N), 10, 512, 0xC3A, pow(3, 2 * N - 1, 2 * N))
+
+
+def test_cfg5_whole_batch_crosscheck_and_permutation():
+    N = 1 << 16
+    _whole_batch_keyswitch_crosscheck(N, mnist_ring_moduli(N), 6, 16, 0xC5A, pow(3, 2 * N - 1, 2 * N))
+
+
+# ---------------------------------------------------------------------------------------------------
+# cfg#2 at the bench shape itself: batch 1024 in 256-ciphertext chunks, the oracle on both sides of every chunk boundary
+# ---------------------------------------------------------------------------------------------------
+def test_cfg2_bench_shape_batch_1024():
+    N, L, t, batch = 1 << 14, 8, 65537, 1024
+    ch = H.chain(50, 17, N)
+    qs = ch[:L]
+    ctx = tf.Context(N, ch)
+    plan = tf.BfvPlan(ctx, ctx, t, idx_s=list(range(L)))
+    d1, d2 = device_uniform(ctx, L, batch * 2, 0xC21), device_uniform(ctx, L, batch * 2, 0xC22)
+    rng = np.random.default_rng(1024)
+    evk = H.uniform_evk(rng, qs, L, N)
+    devk = dev(evk)
+    do = tf.DeviceBuffer(batch * 2 * L * N)
+    plan.mul_relin(devk.ptr, L, d1.ptr, d2.ptr, do.ptr, batch)      # default chunk (256): what bench.py times
+    picks = [0, 255, 256, 511, 512, 1023]
+    c1, c2 = fetch(d1, (batch, 2, L, N), picks), fetch(d2, (batch, 2, L, N), picks)
+    rs, rb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, ch)
+    want = rs.keyswitch(L, False, evk, ref_cpu.bfv_mul(rs, rb, t, c1, c2))
+    assert np.array_equal(fetch(do, (batch, 2, L, N), picks), want)
+    # every ciphertext of the batch: another chunking (96: ragged last chunk) must give the same bits
+    do2 = tf.DeviceBuffer(batch * 2 * L * N)
+    plan.set_chunk(96)
+    plan.mul_relin(devk.ptr, L, d1.ptr, d2.ptr, do2.ptr, batch)
+    plan.set_chunk(0)
+    a = do.to_numpy((batch, 2, L, N))
+    assert np.array_equal(do2.to_numpy((batch, 2, L, N)), a)
+    # and commutativity on the whole batch
+    plan.mul_relin(devk.ptr, L, d2.ptr, d1.ptr, do2.ptr, batch)
+    assert np.array_equal(do2.to_numpy((batch, 2, L, N)), a)

@@ -395,11 +395,46 @@ def test_keyswitch_window_matches_oracle(N, bits, L, w):
                                   [[list(map(int, l)) for l in c] for c in ct[b]], ring, ring, False, relin_window=w)
             assert np.array_equal(got[b], np.array(want, dtype=np.uint64)), (polys, b)
     with pytest.raises(tf.UsageError):
-        ctx.keyswitch_window(L, w, devk.ptr, nwin + 1, devk.ptr, 2, devk.ptr, 1)      # key / ring mismatch
+        ctx.keyswitch_window(L, w, devk.ptr, nwin - 1, devk.ptr, 2, devk.ptr, 1)      # too few key components for this ring
     with pytest.raises(AssertionError):
         ctx.keyswitch_window(L, 33, devk.ptr, nwin, devk.ptr, 2, devk.ptr, 1)
     with pytest.raises(AssertionError):
         ctx.keyswitch_window(L, w, devk.ptr, nwin, devk.ptr, 4, devk.ptr, 1)           # rlwe_she.jl:318
+
+
+@pytest.mark.parametrize("N,bits,Lk,level,w", [(32, 40, 3, 2, 10), (64, 50, 4, 3, 16), (64, 50, 4, 2, 7), (2048, 50, 3, 2, 20), (16, 61, 2, 1, 32)])
+def test_keyswitch_window_with_special_prime_matches_oracle(N, bits, Lk, level, w):
+    """ModulusRaised + digit window (rlwe_she.jl:330-338 under modulusraising.jl:35-49): the base-2^w digits of c[end] over
+    the ciphertext modulus, keys over the key ring restricted to [q_1..q_l, P], P c raised and the sums contracted by
+    floor(./P); at the top level and at a lower level of the same key (more key components than digits), bit-exact against
+    the spec oracle."""
+    qs = H.chain(bits, Lk, N)
+    keyring, cring = spec.Ring(N, qs), spec.Ring(N, qs[:level])
+    nkey = spec.ndigits(spec.Ring(N, qs[:Lk - 1]).Q * qs[-1], 2 ** w)   # a key made over Q P has ndigits(Q P) components
+    need = spec.ndigits(cring.Q, 2 ** w)
+    assert nkey >= need
+    rng = np.random.default_rng(N + w + level)
+    ctx = tf.Context(N, qs)
+    evk = np.stack([H.rand_residues(rng, qs, (2,), N) for _ in range(nkey)])            # [nkey][2][Lk][N], coefficient domain
+    evk_ntt = np.array([[spec.poly_nntt([list(map(int, l)) for l in comp], keyring) for comp in pair] for pair in evk], dtype=np.uint64)
+    devk = dev(evk_ntt)
+    batch = 3
+    for polys in (2, 3):
+        ct = H.rand_residues(rng, qs[:level], (batch, polys), N)
+        ct[0, polys - 1, :, 0] = 0
+        ct[0, polys - 1, :, 1] = [q - 1 for q in qs[:level]]
+        ct[0, polys - 1, :, 2] = 1
+        dct, dout = dev(ct), tf.DeviceBuffer(batch * 2 * level * N)
+        ctx.keyswitch_window(level, w, devk.ptr, nkey, dct.ptr, polys, dout.ptr, batch, key_limbs=Lk, special=True)
+        got = dout.to_numpy((batch, 2, level, N))
+        for b in range(batch):
+            want = spec.keyswitch([([list(map(int, l)) for l in p[0]], [list(map(int, l)) for l in p[1]]) for p in evk],
+                                  [[list(map(int, l)) for l in c] for c in ct[b]], cring, keyring, True, relin_window=w)
+            assert np.array_equal(got[b], np.array(want, dtype=np.uint64)), (polys, b)
+    with pytest.raises(tf.UsageError):
+        ctx.keyswitch_window(level, w, devk.ptr, need - 1, devk.ptr, 2, devk.ptr, 1, key_limbs=Lk, special=True)
+    with pytest.raises(tf.UsageError):
+        ctx.keyswitch_window(Lk, w, devk.ptr, nkey, devk.ptr, 2, devk.ptr, 1, key_limbs=Lk, special=True)   # no room for P
 
 
 @pytest.mark.parametrize("N,qspec,batch", [(2048, "60x3", 3), (1 << 12, "mixed", 40), (1 << 14, "50x4", 5), (1 << 15, "50x3", 2),

@@ -106,6 +106,29 @@ def test_bfv_keyswitch_window():
     assert len(sw2) == 2 and tf.decrypt(kp2, sw2)[0] == 2           # 9 mod 7
 
 
+def test_ckks_modraise_with_digit_window():
+    """test/ckks_modraise.jl:10-33 with a digit-window key instead of the RNS gadget (relin_window = 8 under ModulusRaised,
+    rlwe_she.jl:330-338 + modulusraising.jl:28-49): x*x -> keyswitch -> decrypt, and a rotation, at N = 64."""
+    n = 64
+    R = tf.NegacyclicRing(n, chain(2**40 + 1, 4, n))                # ciphertext ring 3 x 40 bits (the product's scale is 2^80) + P
+    params = tf.ModulusRaised(tf.CKKSParams(R, 8, 3.2))
+    rng = np.random.default_rng(11)
+    kp = tf.keygen(rng, params)
+    scale = 2**40
+    x = (np.arange(1, n // 2 + 1) / 8).astype(complex)
+    c = tf.encrypt(rng, kp, tf.ckks_encode(x, params.R_cipher(), scale), scale=scale)
+    ek = tf.keygen_evalmult(rng, kp.priv)
+    assert len(ek.key.key) == -(-R.modulus().bit_length() // 8)     # ndigits(Q P, base = 2^8): the parent's gadget over the key ring
+    sq = tf.keyswitch(ek, c * c)
+    assert len(sq) == 2
+    got = tf.ckks_decode(tf.decrypt(kp, sq), sq.scale)
+    assert np.abs(got - x * x).max() < 1e-6
+    gk = tf.keygen_galois(rng, kp.priv, steps=1)
+    r = tf.rotate(gk, c)
+    got = tf.ckks_decode(tf.decrypt(kp, r), r.scale)
+    assert np.abs(got - np.roll(x, 1)).max() < 1e-6
+
+
 def test_bfv_superset_extension_basis_batch():
     """the bench's basis relation (ℛbig ⊇ ℛ) on a batch of ciphertexts, slot-wise check of 6*7 etc."""
     n, t = 1024, 65537

@@ -17,7 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import toyfhe_jl_amd as tf
 from oracle import ref_cpu            # checker only
 
-scale = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+HBM_PEAK_GBS = 8000.0
+RECORDS = []                          # one dict per case (bench.py puts them into its JSON line as `other_configs`)
 
 
 def chain(start, n, N):
@@ -81,7 +82,16 @@ def keyswitch_case(name, N, qs, b):
     t_rot = timed(ctx, lambda: ctx.rotate(Lk, level, True, evk.ptr, Lk, g, ct.ptr, out.ptr, b))
     t_rs = timed(ctx, lambda: ctx.rescale(ct.ptr, res.ptr, b * 2, level))
     print(f"{name}: N=2^{N.bit_length() - 1}, level {level} (+special), batch {b}: keyswitch {b / t_ks:9.0f}/s  rotate {b / t_rot:9.0f}/s  "
-          f"rescale {b / t_rs:9.0f} ct/s   [oracle-checked]")
+          f"rescale {b / t_rs:9.0f} ct/s   [oracle-checked]", file=sys.stderr)
+    # algorithmic bytes per unit (BASELINE.md section 3 / SURVEY 8d): a key switch reads the ciphertext (2 polys) and writes 2
+    # polys at the ciphertext's level (the key is shared by the batch); a rescale reads `level` and writes `level - 1` limbs
+    ks_bytes, rs_bytes = 4 * level * N * 8, 2 * (2 * level - 1) * N * 8
+    RECORDS.append({"config": name, "N": N, "level": level, "special_prime": True, "batch": b, "oracle_checked": True,
+                    "moduli_bits": [int(q).bit_length() for q in qs],
+                    "keyswitch_per_s": b / t_ks, "rotate_per_s": b / t_rot, "rescale_ct_per_s": b / t_rs,
+                    "keyswitch_algorithmic_GBs": b / t_ks * ks_bytes / 1e9, "keyswitch_frac_of_hbm_peak": b / t_ks * ks_bytes / 1e9 / HBM_PEAK_GBS,
+                    "rescale_algorithmic_GBs": b / t_rs * rs_bytes / 1e9, "rescale_frac_of_hbm_peak": b / t_rs * rs_bytes / 1e9 / HBM_PEAK_GBS,
+                    "limb_ntts_per_keyswitch": level * (level + 1) + 2 * (level + 1)})
     return ctx, ref
 
 
@@ -99,20 +109,43 @@ def ntt_case(name, N, qs, polys):
     gb = polys * L * N * 16 / 1e9
     t_f = timed(ctx, lambda: ctx.nntt(a.ptr, b2.ptr, polys, L))
     t_i = timed(ctx, lambda: ctx.inntt(b2.ptr, c.ptr, polys, L))
-    print(f"{name}: N=2^{N.bit_length() - 1}, {L} limbs, {polys} polys: NTT fwd {gb / t_f:6.0f} GB/s  inv {gb / t_i:6.0f} GB/s   [oracle-checked]")
+    print(f"{name}: N=2^{N.bit_length() - 1}, {L} limbs, {polys} polys: NTT fwd {gb / t_f:6.0f} GB/s  inv {gb / t_i:6.0f} GB/s   [oracle-checked]", file=sys.stderr)
+    RECORDS.append({"config": "NTT " + name, "N": N, "limbs": L, "polys": polys, "oracle_checked": True,
+                    "moduli_bits": [int(q).bit_length() for q in qs], "bytes_per_pass": polys * L * N * 16,
+                    "fwd_GBs": gb / t_f, "inv_GBs": gb / t_i, "fwd_frac_of_hbm_peak": gb / t_f / HBM_PEAK_GBS,
+                    "inv_frac_of_hbm_peak": gb / t_i / HBM_PEAK_GBS})
 
 
-N = 1 << 15
-keyswitch_case("cfg#3", N, chain(2**40 + 1, 11, N), max(8, 512 // scale))
-N = 1 << 14
-keyswitch_case("cfg#4", N, chain(2**50 + 1, 7, N), max(8, 512 // scale))
-N = 1 << 16
-q0, ps = chain(2**60 + 1, 2, N)
-mnist = [q0] + chain(2**40 + 1, 5, N) + [ps]
-keyswitch_case("cfg#5 (infer.jl ring 60+5x40+60 bit)", N, mnist, max(8, 64 // scale))
-keyswitch_case("cfg#5' (7 x 50 bit)", N, chain(2**50 + 1, 7, N), max(8, 64 // scale))
-ntt_case("cfg#5 (infer.jl ring)", N, mnist, max(8, 128 // scale))
-ntt_case("cfg#5' (7 x 50 bit)", N, chain(2**50 + 1, 7, N), max(8, 128 // scale))
-N = 1 << 14
-ntt_case("60-bit primes", N, chain(2**60 + 1, 8, N), max(8, 1024 // scale))
-ntt_case("50-bit primes", N, chain(2**50 + 1, 8, N), max(8, 1024 // scale))
+def run(scale=1, out=None):
+    """All cases; returns the list of records (each case asserts one ciphertext against the oracle before it is timed).  A case that
+    fails is recorded as {"config": ..., "error": ...} and does not stop the others."""
+    del RECORDS[:]
+
+    def guarded(f, name, *a):
+        try:
+            f(name, *a)
+        except Exception as e:  # noqa: BLE001
+            RECORDS.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+
+    N = 1 << 15
+    guarded(keyswitch_case, "cfg#3 CKKS N=2^15 10x40-bit + special prime (ckks_rotate.jl path)", N, chain(2**40 + 1, 11, N), max(8, 512 // scale))
+    N = 1 << 14
+    guarded(keyswitch_case, "cfg#4 N=2^14 6x50-bit + special prime (keyswitch with RNS basis extension)", N, chain(2**50 + 1, 7, N), max(8, 512 // scale))
+    N = 1 << 16
+    q0, ps = chain(2**60 + 1, 2, N)
+    mnist = [q0] + chain(2**40 + 1, 5, N) + [ps]
+    guarded(keyswitch_case, "cfg#5 N=2^16 infer.jl ring 60+5x40+60 bit", N, mnist, max(8, 64 // scale))
+    guarded(keyswitch_case, "cfg#5' N=2^16 7x50 bit", N, chain(2**50 + 1, 7, N), max(8, 64 // scale))
+    guarded(ntt_case, "cfg#5 N=2^16 infer.jl ring", N, mnist, max(8, 128 // scale))
+    guarded(ntt_case, "cfg#5' N=2^16 7x50 bit", N, chain(2**50 + 1, 7, N), max(8, 128 // scale))
+    N = 1 << 14
+    guarded(ntt_case, "N=2^14 60-bit primes", N, chain(2**60 + 1, 8, N), max(8, 1024 // scale))
+    guarded(ntt_case, "N=2^14 50-bit primes", N, chain(2**50 + 1, 8, N), max(8, 1024 // scale))
+    return list(RECORDS)
+
+
+if __name__ == "__main__":
+    import json
+    recs = run(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    for r in recs:
+        print(json.dumps(r))

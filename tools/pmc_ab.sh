@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp; export TMPDIR=/tmp
 for w in "$@"; do
   OUT=$R/gpurun_out/$OUTTAG/pmc_$w; mkdir -p $OUT
-  CMD="python $R/bench.py --steps 1 --warmup 1 --batch 256 --no-cpu --no-ntt"
+  CMD="python $R/bench.py --steps 1 --warmup 1 --batch 256 --no-cpu --no-ntt --no-configs"
   TFHE_HIP_LIB=$R/tools/ab_$w.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU -d $OUT/pmc_SQ -o p --output-format csv -- $CMD > $OUT/sq.log 2>&1
   TFHE_HIP_LIB=$R/tools/ab_$w.so rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM -d $OUT/pmc_GRBM -o p --output-format csv -- $CMD > $OUT/grbm.log 2>&1
   python $R/tools/pmc_bench.py $OUT 256 $w > $R/gpurun_out/$OUTTAG/${w}_pmc.json

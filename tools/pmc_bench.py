@@ -6,8 +6,18 @@ SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*; SQ_INSTS_* count wave instructions)
 the dispatch, reported as the SUM over the 8 XCDs: a 2.2 ms kernel shows 35 M, i.e. 8 x 2.0 GHz x 2.2 ms) and the dispatch durations of the GRBM pass, from which the effective clock and the VALU issue utilisation
 follow:  valu_util = SQ_INSTS_VALU x 4 clk / (1024 SIMDs x GRBM_GUI_ACTIVE / 8).
 usage: pmc_bench.py <dir with pmc_*/> <ciphertexts per launch> <tag> > profiles/pmc_bench_kernels.json"""
-import csv, glob, json, os, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
 root, batch, tag = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+
+
+def source_id():  # same as bench.py source_id(): which sources the profiled library was built from
+    R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    src = os.path.join(R, "toyfhe.jl_amd", "csrc")
+    for f in sorted(os.listdir(src)) + [os.path.join("..", "..", "include", "toyfhe_hip.h")]:
+        h.update(f.encode())
+        h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
 FETCH_CAL, WRITE_CAL, N_SIMD, N_XCD = 2.0, 1.0, 1024, 8
 
 
@@ -35,7 +45,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
 out = {"method": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv, separate passes (FETCH_SIZE | WRITE_SIZE | 8 SQ counters | "
                  "GRBM_GUI_ACTIVE + SQ_INSTS_LDS/SALU + SQ_WAVES) over `bench.py --steps 1 --warmup 0 --batch 256 --no-cpu --no-ntt`; "
                  "FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE x2 (gfx950); per-kernel sums over the launches",
-       "batch": batch, "note": f"{tag}: one launch of each fused kernel covers {batch} ciphertexts", "kernels": {}}
+       "batch": batch, "source_id": source_id(), "note": f"{tag}: one launch of each fused kernel covers {batch} ciphertexts", "kernels": {}}
 for k, c in sorted(kern.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):
     n = max(len(s) for s in launch[k].values())
     e = {"launches": n}

@@ -10,8 +10,8 @@ TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p "$OUT" && cd /tmp && export TMPDIR=/tmp
-BENCH1="python $R/bench.py --steps 1 --warmup 0 --batch 256 --no-cpu --no-ntt"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- python "$R/bench.py" --no-cpu --no-ntt > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err"
+BENCH1="python $R/bench.py --steps 1 --warmup 0 --batch 256 --no-cpu --no-ntt --no-configs"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- python "$R/bench.py" --no-cpu --no-ntt --no-configs > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err"
 python "$R/tools/csv_kernel_stats.py" "$OUT/trace" > "$OUT/${TAG}_bench_kernel_stats.txt" 2>> "$OUT/trace.err"
 pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/pmc_$name" -o p --output-format csv -- $BENCH1 > "$OUT/pmc_$name.log" 2>&1; }
 pass FETCH_SIZE FETCH_SIZE

@@ -133,8 +133,11 @@ TFHE_HD void conv_words(const conv_tab_t& T, const u64* xi, int stride, u32 alph
 // Base-2^w digits of one coefficient (key switch with relin_window = w, rlwe_she.jl:333-337): digit i of
 // convert(Integer, x), x in [0, A) rebuilt exactly from the residues c[l*ls] (a single limb is its own integer);
 // digit i is written to d[i*ds_digit + l*ds_limb] for every limb l (the same small value in each).
+// nlw: limb rows written per digit (level, or level + 1 when the special prime's limb rides along: the digit is below every
+// modulus, so its residue is the digit itself)
 TFHE_HD void window_digits_coeff(const conv_tab_t* T, const u64* c, size_t ls, int level, int wbits, int nwin, u64* d,
-                                 size_t ds_digit, size_t ds_limb) {
+                                 size_t ds_digit, size_t ds_limb, int nlw = -1) {
+    if (nlw < 0) nlw = level;
     u64 words[TFHE_MAX_LIMBS + 1];
     int nwords = 1;
     if (level == 1) {
@@ -153,7 +156,7 @@ TFHE_HD void window_digits_coeff(const conv_tab_t* T, const u64* c, size_t ls, i
         u64 v = wd < nwords ? words[wd] >> off : 0;
         if (off + wbits > 64 && wd + 1 < nwords) v |= words[wd + 1] << (64 - off);
         v &= mask;
-        for (int l = 0; l < level; l++) d[(size_t)i * ds_digit + (size_t)l * ds_limb] = v;
+        for (int l = 0; l < nlw; l++) d[(size_t)i * ds_digit + (size_t)l * ds_limb] = v;
     }
 }
 

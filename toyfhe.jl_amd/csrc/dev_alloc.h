@@ -11,13 +11,21 @@
 //                   same size, or falls back to hipMalloc; on out-of-memory the cache is drained and the call retried.
 //
 // So a recycled block is never handed out while a kernel enqueued before its tfhe_free can still touch it, whatever stream
-// the next user runs on.  TFHE_ALLOC_CACHE=0 in the environment restores plain hipMalloc / hipFree.  Per device; a mutex
-// guards the tables (contexts on different host threads share the allocator).
+// the next user runs on.  TFHE_ALLOC_CACHE=0 in the environment restores plain hipMalloc / hipFree.
+//
+// Per device: a block is cached, parked and handed out again only on the device it was allocated on (the current device of
+// the calling thread, tfhe_set_device), and its release events are recorded only on the streams of contexts of that device.
+// One mutex guards the tables (contexts on different host threads share the allocator); a context's stream slot is read
+// and re-pointed under it (set_stream).  The cache is bounded by a third of the device's memory (at most 96 GiB), and every
+// other device allocation of the library goes through malloc_retry, which gives the cache back before reporting
+// out-of-memory.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -31,16 +39,28 @@ struct parked_t {
     size_t bytes;
     std::vector<hipEvent_t> evs;
 };
+struct live_t {
+    size_t bytes;
+    int dev;
+};
+struct stream_slot_t {
+    hipStream_t* sp;  // &ctx->stream
+    int dev;
+};
+struct dev_state_t {  // the cache of one device
+    std::unordered_map<size_t, std::vector<void*>> ready;        // size -> recyclable blocks
+    std::deque<parked_t> parked;                                 // freed, waiting for their events
+    std::vector<hipEvent_t> ev_pool;                             // events of this device
+    size_t cached_bytes = 0, max_cached = 0;
+};
 
 struct state_t {
     std::mutex mu;
     bool enabled = true, init = false;
-    std::vector<hipStream_t*> streams;                           // &ctx->stream of every live context
-    std::unordered_map<void*, size_t> live;                      // block -> size (handed out)
-    std::unordered_map<size_t, std::vector<void*>> ready;        // size -> recyclable blocks
-    std::deque<parked_t> parked;                                 // freed, waiting for their events
-    std::vector<hipEvent_t> ev_pool;
-    size_t cached_bytes = 0, live_bytes = 0, max_cached = (size_t)96 << 30;
+    std::vector<stream_slot_t> streams;                          // stream slot of every live context, with its device
+    std::unordered_map<void*, live_t> live;                      // block -> size, device (handed out)
+    std::map<int, dev_state_t> devs;
+    size_t cached_bytes = 0, live_bytes = 0;
     long n_hip_malloc = 0, n_reuse = 0;
 };
 inline state_t& S() {
@@ -53,45 +73,81 @@ inline void lazy_init(state_t& s) {
     const char* e = getenv("TFHE_ALLOC_CACHE");
     if (e && e[0] == '0') s.enabled = false;
 }
+inline int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    return d;
+}
+inline dev_state_t& dev_locked(state_t& s, int dev) {
+    dev_state_t& d = s.devs[dev];
+    if (d.max_cached == 0) {
+        size_t fr = 0, tot = 0;
+        d.max_cached = (size_t)96 << 30;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) d.max_cached = std::min(d.max_cached, tot / 3);
+        else (void)hipGetLastError();
+    }
+    return d;
+}
 
 inline void register_stream(hipStream_t* sp) {
     state_t& s = S();
     std::lock_guard<std::mutex> g(s.mu);
-    s.streams.push_back(sp);
+    s.streams.push_back(stream_slot_t{sp, current_device()});
 }
 inline void unregister_stream(hipStream_t* sp) {
     state_t& s = S();
     std::lock_guard<std::mutex> g(s.mu);
     for (size_t i = 0; i < s.streams.size(); i++)
-        if (s.streams[i] == sp) { s.streams.erase(s.streams.begin() + i); break; }
+        if (s.streams[i].sp == sp) { s.streams.erase(s.streams.begin() + i); break; }
+}
+// re-point a registered stream slot (tfhe_ctx_set_stream): release() reads the slot under the same mutex
+inline void set_stream(hipStream_t* sp, hipStream_t v) {
+    state_t& s = S();
+    std::lock_guard<std::mutex> g(s.mu);
+    *sp = v;
 }
 
 // move parked blocks whose events have all completed to the ready lists (front of the queue first; stop at the first busy one)
-inline void poll_locked(state_t& s) {
-    while (!s.parked.empty()) {
-        parked_t& b = s.parked.front();
+inline void poll_locked(dev_state_t& d) {
+    while (!d.parked.empty()) {
+        parked_t& b = d.parked.front();
         bool done = true;
         for (hipEvent_t ev : b.evs)
             if (hipEventQuery(ev) != hipSuccess) { done = false; break; }
         if (!done) { (void)hipGetLastError(); break; }
-        for (hipEvent_t ev : b.evs) s.ev_pool.push_back(ev);
-        s.ready[b.bytes].push_back(b.p);
-        s.parked.pop_front();
+        for (hipEvent_t ev : b.evs) d.ev_pool.push_back(ev);
+        d.ready[b.bytes].push_back(b.p);
+        d.parked.pop_front();
     }
 }
-// give everything cached back to the driver (after draining the device)
+// give everything cached on the CURRENT device back to the driver (after draining it)
 inline void trim_locked(state_t& s) {
+    dev_state_t& d = dev_locked(s, current_device());
     (void)hipDeviceSynchronize();
-    poll_locked(s);
-    for (auto& kv : s.ready)
+    poll_locked(d);
+    for (auto& kv : d.ready)
         for (void* p : kv.second) (void)hipFree(p);
-    s.ready.clear();
-    for (auto& b : s.parked) {
-        for (hipEvent_t ev : b.evs) s.ev_pool.push_back(ev);
+    d.ready.clear();
+    for (auto& b : d.parked) {
+        for (hipEvent_t ev : b.evs) d.ev_pool.push_back(ev);
         (void)hipFree(b.p);
     }
-    s.parked.clear();
-    s.cached_bytes = 0;
+    d.parked.clear();
+    s.cached_bytes -= d.cached_bytes;
+    d.cached_bytes = 0;
+}
+// hipMalloc for the library's long-lived allocations (workspaces, tables): on out-of-memory the cache is given back first
+template <class T>
+inline hipError_t malloc_retry(T** out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        state_t& s = S();
+        std::lock_guard<std::mutex> g(s.mu);
+        trim_locked(s);
+        e = hipMalloc(out, bytes);
+    }
+    return e;
 }
 
 inline hipError_t alloc(size_t bytes, void** out) {
@@ -100,11 +156,14 @@ inline hipError_t alloc(size_t bytes, void** out) {
     lazy_init(s);
     if (bytes == 0) bytes = 8;
     if (!s.enabled) return hipMalloc(out, bytes);
-    poll_locked(s);
-    auto it = s.ready.find(bytes);
-    if (it != s.ready.end() && !it->second.empty()) {
+    const int dev = current_device();
+    dev_state_t& d = dev_locked(s, dev);
+    poll_locked(d);
+    auto it = d.ready.find(bytes);
+    if (it != d.ready.end() && !it->second.empty()) {
         *out = it->second.back();
         it->second.pop_back();
+        d.cached_bytes -= bytes;
         s.cached_bytes -= bytes;
         s.n_reuse++;
     } else {
@@ -117,7 +176,7 @@ inline hipError_t alloc(size_t bytes, void** out) {
         if (e != hipSuccess) return e;
         s.n_hip_malloc++;
     }
-    s.live[*out] = bytes;
+    s.live[*out] = live_t{bytes, dev};
     s.live_bytes += bytes;
     return hipSuccess;
 }
@@ -129,27 +188,42 @@ inline hipError_t release(void* p) {
     lazy_init(s);
     auto it = s.live.find(p);
     if (it == s.live.end()) return hipFree(p);                  // not ours (allocated while the cache was off)
-    const size_t bytes = it->second;
+    const size_t bytes = it->second.bytes;
+    const int dev = it->second.dev;
     s.live.erase(it);
     s.live_bytes -= bytes;
     if (!s.enabled) return hipFree(p);
+    // events and the cache of the block's own device (the caller may have switched devices since the allocation)
+    const int cur = current_device();
+    if (cur != dev && hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return hipFree(p); }
+    dev_state_t& d = dev_locked(s, dev);
     parked_t b{p, bytes, {}};
-    for (hipStream_t* sp : s.streams) {
+    hipError_t rc = hipSuccess;
+    bool park = true;
+    for (const stream_slot_t& sl : s.streams) {
+        if (sl.dev != dev) continue;                             // work on other devices cannot touch this block
         hipEvent_t ev;
-        if (!s.ev_pool.empty()) { ev = s.ev_pool.back(); s.ev_pool.pop_back(); }
-        else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return hipFree(p); }
-        if (hipEventRecord(ev, *sp) != hipSuccess) {           // a stream the caller has destroyed: fall back to the safe path
+        if (!d.ev_pool.empty()) { ev = d.ev_pool.back(); d.ev_pool.pop_back(); }
+        else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); park = false; break; }
+        if (hipEventRecord(ev, *sl.sp) != hipSuccess) {         // a stream the caller has destroyed: fall back to the safe path
             (void)hipGetLastError();
-            s.ev_pool.push_back(ev);
-            for (hipEvent_t e2 : b.evs) s.ev_pool.push_back(e2);
-            return hipFree(p);
+            d.ev_pool.push_back(ev);
+            park = false;
+            break;
         }
         b.evs.push_back(ev);
     }
-    s.parked.push_back(std::move(b));
-    s.cached_bytes += bytes;
-    if (s.cached_bytes > s.max_cached) trim_locked(s);
-    return hipSuccess;
+    if (park) {
+        d.parked.push_back(std::move(b));
+        d.cached_bytes += bytes;
+        s.cached_bytes += bytes;
+        if (d.cached_bytes > d.max_cached) trim_locked(s);
+    } else {
+        for (hipEvent_t e2 : b.evs) d.ev_pool.push_back(e2);
+        rc = hipFree(p);                                         // synchronising free
+    }
+    if (cur != dev) (void)hipSetDevice(cur);
+    return rc;
 }
 
 }  // namespace devalloc

@@ -3,6 +3,7 @@
 // thread per coefficient for the cross-limb kernels.  Integer work: no MFMA by design.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "bfv_core.h"
 #include "bfv_fast.h"
 #include "ntt_core.h"
@@ -1383,9 +1384,50 @@ __device__ __forceinline__ void kst(unsigned tag) {
 #endif
 // ---- shared pieces of the fused kernels: a forward transform that ends in registers (last pass's natural-order map)
 // and an inverse transform that starts from registers in that same map ----
-template <class A, int LOGB, int LOGT, bool PRELIFT = false>
+// middle-pass twiddles of the fused kernels from LDS tables (ArithFpL), per kernel: bit 0 -- forward transforms, bit 1 -- inverse
+// transforms (those keep their register prefetch when the bit is clear); 0: vector loads throughout, no tables.
+// MEASURED (r03, rocprof on one box, alternating bench runs): key switch 1 445 / 1 452 us with the forward / both tables against
+// 1 455 us without, the core kernel 1 905 against 1 870 us (+ 2 %), step 59.9 k against 59.8 k -- nothing: with the twiddles
+// pinned to one cache line (-DTFHE_ABL_NOTW=3) the two kernels gain 5 %, which is the whole prize, and the LDS reads cost
+// about what the L2 round trips did.  Off by default; the code stays as the record of the experiment.
+#ifndef TFHE_TWL_KS
+#define TFHE_TWL_KS 0
+#endif
+#ifndef TFHE_TWL_CORE
+#define TFHE_TWL_CORE 0
+#endif
+// words of the LDS twiddle tables of the fused kernels (one per direction): every stage below the boundary pass
+template <int LOGB, int LOGT>
+constexpr u32 fused_tw_entries() {
+    return 1u << (pass_k_fwd(LOGB, LOGT, 0) + pass_k_fwd(LOGB, LOGT, pass_k_fwd(LOGB, LOGT, 0)));
+}
+template <int LOGB, int LOGT>
+constexpr u32 fused_tw_words() {  // padded (tw_lds_pos)
+    return fused_tw_entries<LOGB, LOGT>() + (fused_tw_entries<LOGB, LOGT>() >> 4);
+}
+// fill the LDS twiddle tables of limb `C` (ArithFpL); the first reader is behind the barrier that follows the first pass, and
+// the previous item's last reader (its inverse middle pass) is behind the barrier that precedes its last pass
+template <class A, int LOGB, int LOGT, int MASK>
+__device__ __forceinline__ void fused_fill_tw(u64* lds, typename A::ctx& C) {
+    constexpr u32 TE = fused_tw_entries<LOGB, LOGT>(), T = 1u << LOGT;
+    static_assert(TE % T == 0, "table size vs workgroup size");
+    double* wl = reinterpret_cast<double*>(lds + lds_words<LOGB, LOGT>());
+    double* wil = wl + fused_tw_words<LOGB, LOGT>();
+    const u32 tid = fresh_tid();
+    typedef __attribute__((address_space(1))) const double* gptr_t;
+    const gptr_t gw = (gptr_t)C.W, gwi = (gptr_t)C.Winv;
+#pragma unroll
+    for (u32 i = 0; i < TE; i += T) {
+        if (MASK & 1) wl[tw_lds_pos(i + tid)] = gw[i + tid];
+        if (MASK & 2) wil[tw_lds_pos(i + tid)] = gwi[i + tid];
+    }
+    C.Wl = wl;
+    C.Winvl = wil;
+}
+template <class A, int LOGB, int LOGT, bool PRELIFT = false, bool TWL = false>
 __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, const typename A::ctx& C, bool& first,
                                                   typename A::elem* v, const lift_t* lift = nullptr) {
+    typedef typename std::conditional<TWL, ArithFpL, A>::type AM;  // policy of the middle pass
     constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
     constexpr int E = 1 << (LOGB - LOGT);
     const u32 tid = fresh_tid();
@@ -1416,7 +1458,7 @@ __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, con
     }
     __syncthreads();
     kst(2);
-    ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
+    ntt_fwd_pass<AM, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
     __syncthreads();
     kst(3);
     {
@@ -1434,7 +1476,7 @@ __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, con
 // (+ addend) to gdst
 // SCALE = false: the caller has folded N^-1 into its operands (k_ks_fused: into the key rows), the last stage is a plain
 // butterfly instead of two scaling products per pair
-template <class A, int LOGB, int LOGT, bool SCALE = true>
+template <class A, int LOGB, int LOGT, bool SCALE = true, bool TWL = false>
 __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* v, u64* gdst, const typename A::ctx& C, const u64* addend) {
     constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB);
     constexpr int E = 1 << (LOGB - LOGT);
@@ -1442,16 +1484,31 @@ __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* 
     __syncthreads();  // the previous transform's last pass has read LDS
     constexpr int S1 = LOGB - KI1, K2 = pass_k_inv(LOGB, LOGT, S1);
     typedef pgeom<LOGB, LOGT, S1 - K2, K2> G2;
-    typename A::tw tw_next[G2::SETS * G2::NTW];  // middle-pass twiddles, requested before the exchange
-    {
+    if constexpr (TWL) {
+        // middle pass with its twiddles from the LDS table (no register prefetch, no vector loads), last pass as before
+        static_assert(S1 - K2 != 0, "three-pass inverse expected");
+        {
 #pragma unroll
-        for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], C.p, C.pinv);
-        inv_compute<A, LOGB, LOGT, S1, KI1, true, SCALE, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, 1u);
-        if constexpr (S1 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S1 - K2, K2, false>(tw_next, C, tid, 1u);
-        inv_store<A, LOGB, LOGT, S1, KI1, true, SCALE>(v, lds, nullptr, C, tid);
+            for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], C.p, C.pinv);
+            inv_compute<A, LOGB, LOGT, S1, KI1, true, SCALE, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, 1u);
+            inv_store<A, LOGB, LOGT, S1, KI1, true, SCALE>(v, lds, nullptr, C, tid);
+        }
+        __syncthreads();
+        ntt_inv_pass<ArithFpL, LOGB, LOGT, S1 - K2, K2, false, false, SCALE>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
+        __syncthreads();
+        ntt_inv_pass<A, LOGB, LOGT, 0, S1 - K2, false, true, SCALE>(lds, nullptr, gdst, C, tid, 1u, 0, 0u, addend);
+    } else {
+        typename A::tw tw_next[G2::SETS * G2::NTW];  // middle-pass twiddles, requested before the exchange
+        {
+#pragma unroll
+            for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], C.p, C.pinv);
+            inv_compute<A, LOGB, LOGT, S1, KI1, true, SCALE, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, 1u);
+            if constexpr (S1 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S1 - K2, K2, false>(tw_next, C, tid, 1u);
+            inv_store<A, LOGB, LOGT, S1, KI1, true, SCALE>(v, lds, nullptr, C, tid);
+        }
+        __syncthreads();
+        inv_schedule_ptw<A, LOGB, LOGT, S1, SCALE>(lds, nullptr, gdst, C, tid, 1u, addend, tw_next);
     }
-    __syncthreads();
-    inv_schedule_ptw<A, LOGB, LOGT, S1, SCALE>(lds, nullptr, gdst, C, tid, 1u, addend, tw_next);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1485,6 +1542,10 @@ __global__ __launch_bounds__(256) void k_evk_to_f64(const u64* __restrict__ evk,
     }
 }
 // PRELIFT: the rows of c[end] arrive as centred doubles (bfv_contract_narrow<.., LIFTED>): the lift is a bit cast
+template <int LOGB, int LOGT, int MASK>
+constexpr size_t fused_lds_bytes() {
+    return ((size_t)lds_words<LOGB, LOGT>() + (MASK ? 2 * (size_t)fused_tw_words<LOGB, LOGT>() : 0)) * 8;
+}
 template <class A, int LOGB, int LOGT, bool PRELIFT = false>
 __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ evd, const u64* __restrict__ ct,
                                                          u64* __restrict__ out, const ntt_limb_t* __restrict__ LT,
@@ -1511,7 +1572,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
         if (item == ~0u) break;
         const u32 b = item / nw, j = item % nw;
         const ntt_limb_t& Lj = LT[KA.w.idx[j]];
-        const typename A::ctx C = A::make(Lj);
+        typename A::ctx C = A::make(Lj);
+        if constexpr (TFHE_TWL_KS != 0) fused_fill_tw<A, LOGB, LOGT, TFHE_TWL_KS>(lds, C);
         lift_t lf;
         lf.qj = Lj.q;
         lf.bj = Lj.br;
@@ -1525,7 +1587,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
             const u64* grow = ct + ((size_t)((b * polys + polys - 1) * level + i) << LOGB);
             typename A::elem v[E];
             kst(1);
-            fused_fwd_to_regs<A, LOGB, LOGT, PRELIFT>(lds, grow, C, first, v, &lf);
+            fused_fwd_to_regs<A, LOGB, LOGT, PRELIFT, (TFHE_TWL_KS & 1) != 0>(lds, grow, C, first, v, &lf);
             // multiply-accumulate with the key: component 1 (masked) feeds out_0, component 0 (mask) feeds out_1
             const u64* e_mask = evd + ((((size_t)i * 2 + 0) * nw + j) << LOGB);    // key words as doubles (k_evk_to_f64)
             const u64* e_masked = evd + ((((size_t)i * 2 + 1) * nw + j) << LOGB);
@@ -1568,7 +1630,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
             if (sidx) kst(6);
             const u64* addend = (!KA.special && (u32)sidx < add_s) ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : nullptr;
             u64* gdst = out + ((size_t)((b * 2 + sidx) * nw + j) << LOGB);
-            fused_inv_from_regs<A, LOGB, LOGT, false>(lds, acc[sidx], gdst, C, addend);  // N^-1 is in the key rows (k_evk_to_f64)
+            fused_inv_from_regs<A, LOGB, LOGT, false, (TFHE_TWL_KS & 2) != 0>(lds, acc[sidx], gdst, C, addend);  // N^-1 is in the key rows (k_evk_to_f64)
         }
         kst(7);
     }
@@ -1745,7 +1807,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
         const u32 item = xcd_limb_walk(it, blockIdx.x, gridDim.x, nb, nitems);
         if (item == ~0u) break;
         const u32 b = item / nb, j = item % nb;
-        const typename A::ctx C = A::make(LT[sel.idx[j]]);
+        typename A::ctx C = A::make(LT[sel.idx[j]]);
+        if constexpr (TFHE_TWL_CORE != 0) fused_fill_tw<A, LOGB, LOGT, TFHE_TWL_CORE>(lds, C);
         const size_t r0 = ((size_t)(b * 2 + 0) * nb + j) << LOGB, r1 = ((size_t)(b * 2 + 1) * nb + j) << LOGB;
         u64* const t0 = T + (((size_t)(b * 3 + 0) * nb + j) << LOGB);
         u64* const t1 = T + (((size_t)(b * 3 + 1) * nb + j) << LOGB);
@@ -1759,13 +1822,13 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
             const size_t s0 = ((size_t)(b * 2 + 0) * alt.ns + alt.idx[j]) << LOGB, s1 = ((size_t)(b * 2 + 1) * alt.ns + alt.idx[j]) << LOGB;
             pa0 = alt.a + s0; pa1 = alt.a + s1; pb0 = alt.b + s0; pb1 = alt.b + s1;
         }
-        fused_fwd_to_regs<A, LOGB, LOGT>(lds, pa0, C, first, A0);
+        fused_fwd_to_regs<A, LOGB, LOGT, false, (TFHE_TWL_CORE & 1) != 0>(lds, pa0, C, first, A0);
 #pragma unroll
         for (int e = 0; e < E; e++) A0[e] = fp_reduce(A0[e], C.p, C.pinv);
-        fused_fwd_to_regs<A, LOGB, LOGT>(lds, pa1, C, first, A1);
+        fused_fwd_to_regs<A, LOGB, LOGT, false, (TFHE_TWL_CORE & 1) != 0>(lds, pa1, C, first, A1);
 #pragma unroll
         for (int e = 0; e < E; e++) A1[e] = fp_reduce(A1[e], C.p, C.pinv);
-        fused_fwd_to_regs<A, LOGB, LOGT>(lds, pb0, C, first, v);
+        fused_fwd_to_regs<A, LOGB, LOGT, false, (TFHE_TWL_CORE & 1) != 0>(lds, pb0, C, first, v);
         {
             const u32 tid = fresh_tid();
 #pragma unroll
@@ -1780,9 +1843,9 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
                     v[e] = fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv);                                // a0 b0, in place
                 }
             }
-            fused_inv_from_regs<A, LOGB, LOGT>(lds, v, t0, C, nullptr);
+            fused_inv_from_regs<A, LOGB, LOGT, true, (TFHE_TWL_CORE & 2) != 0>(lds, v, t0, C, nullptr);
         }
-        fused_fwd_to_regs<A, LOGB, LOGT>(lds, pb1, C, first, v);
+        fused_fwd_to_regs<A, LOGB, LOGT, false, (TFHE_TWL_CORE & 1) != 0>(lds, pb1, C, first, v);
         {
             const u32 tid = fresh_tid();
 #pragma unroll
@@ -1797,8 +1860,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
                     A1[e] = fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv);
                 }
             }
-            fused_inv_from_regs<A, LOGB, LOGT>(lds, A0, t1, C, nullptr);
-            fused_inv_from_regs<A, LOGB, LOGT>(lds, A1, t2, C, nullptr);
+            fused_inv_from_regs<A, LOGB, LOGT, true, (TFHE_TWL_CORE & 2) != 0>(lds, A0, t1, C, nullptr);
+            fused_inv_from_regs<A, LOGB, LOGT, true, (TFHE_TWL_CORE & 2) != 0>(lds, A1, t2, C, nullptr);
         }
     }
 }
@@ -1821,12 +1884,13 @@ __global__ __launch_bounds__(256) void k_ks_digits(const u64* __restrict__ ct, u
 // integer).  dig: [batch][nwin][level][N], the same small value in every limb.  One thread per coefficient.
 __global__ __launch_bounds__(256) void k_ks_window_digits(const u64* __restrict__ ct, u64* __restrict__ dig,
                                                            const conv_tab_t* __restrict__ T, int level, int wbits, int nwin,
-                                                           int polys, u32 n, u32 gx) {
+                                                           int polys, u32 n, u32 gx, int nw) {
     const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
     const size_t b = blockIdx.x / gx;
     if (k >= n) return;
+    // dig [batch][nwin][nw][N], nw = level (+ 1 with the special prime, modulusraising.jl:35-41)
     window_digits_coeff(T, ct + ((b * polys + polys - 1) * level) * n + k, n, level, wbits, nwin,
-                        dig + (b * nwin * level) * n + k, (size_t)level * n, n);
+                        dig + (b * nwin * nw) * n + k, (size_t)nw * n, n, nw);
 }
 
 // out[b][s][j] += c[b][s][j] for the components that have one (N > 2^14 path); rows = batch*2*level

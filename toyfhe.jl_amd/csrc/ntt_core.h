@@ -191,6 +191,9 @@ struct ArithFp {
         const ftwd_t *W, *Winv, *Wb, *Winvb;
         ftw_t ninv, w1n;
         u64 q;
+        // LDS copies of the first 2^(K1+K2) entries of W / Winv (the first and middle passes' twiddles), set by the fused
+        // kernels; read through ArithFpL
+        const ftwd_t *Wl = nullptr, *Winvl = nullptr;
     };
     static TFHE_HD ctx make(const ntt_limb_t& L) {
         return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.Wdb, L.Winvdb, L.ninv_d, L.w1inv_ninv_d, L.q};
@@ -220,10 +223,13 @@ struct ArithFp {
         return ftw_t{tab[i]};
 #endif
     }
-    static TFHE_HD tw ld_fwd(const ctx& c, u32 i) { return ld(c.W, i); }
-    static TFHE_HD tw ld_inv(const ctx& c, u32 i) { return ld(c.Winv, i); }
-    static TFHE_HD tw ld_fwd_b(const ctx& c, u32 i) { return ld(c.Wb, i); }
-    static TFHE_HD tw ld_inv_b(const ctx& c, u32 i) { return ld(c.Winvb, i); }
+#ifndef TFHE_ABL_NOTW  // design aid: bit 0 -- first / middle pass twiddles all from one cache line, bit 1 -- boundary pass
+#define TFHE_ABL_NOTW 0  // (wrong results; same instructions and registers, the loads hit the vector L1)
+#endif
+    static TFHE_HD tw ld_fwd(const ctx& c, u32 i) { return ld(c.W, (TFHE_ABL_NOTW & 1) ? (i & 7u) : i); }
+    static TFHE_HD tw ld_inv(const ctx& c, u32 i) { return ld(c.Winv, (TFHE_ABL_NOTW & 1) ? (i & 7u) : i); }
+    static TFHE_HD tw ld_fwd_b(const ctx& c, u32 i) { return ld(c.Wb, (TFHE_ABL_NOTW & 2) ? (i & 7u) : i); }
+    static TFHE_HD tw ld_inv_b(const ctx& c, u32 i) { return ld(c.Winvb, (TFHE_ABL_NOTW & 2) ? (i & 7u) : i); }
     static TFHE_HD bool has_b(const ctx& c) { return c.Wb != nullptr; }
     static TFHE_HD void bf_fwd(elem& x, elem& y, tw w, const ctx& c) {
 #ifdef TFHE_ABL_NOALU
@@ -251,6 +257,18 @@ struct ArithFp {
     static TFHE_HD u64 out_fwd(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
     static TFHE_HD u64 out_inv_scaled(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
     static TFHE_HD u64 out_inv_lazy(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
+};
+// ArithFp with the middle pass's twiddles read from LDS (ctx::Wl / Winvl, filled once per item by the fused kernels).  In those
+// kernels the middle pass's 31 twiddle words per thread were vector loads requested a few butterflies ahead of their use
+// (256 registers leave no room to request them earlier): every stage began with an exposed L2 round trip in both waves of a
+// SIMD, and the loads shared the in-order vmcnt with the row traffic.  The table is 8 KiB per direction (stages < K1 + K2:
+// 2^10 entries) next to the 132 KiB row image; a 16-lane group reads one entry (broadcast).
+// The table is padded by one word per 16 (entry i at i + (i >> 4)): the 16-lane groups of a wave read entries 2^d apart, which
+// unpadded fall into the same banks for d = 4 (128 bytes apart) and d = 3.
+TFHE_HD u32 tw_lds_pos(u32 i) { return i + (i >> 4); }
+struct ArithFpL : ArithFp {
+    static TFHE_HD tw ld_fwd(const ctx& c, u32 i) { return ftw_t{c.Wl[tw_lds_pos(i)]}; }
+    static TFHE_HD tw ld_inv(const ctx& c, u32 i) { return ftw_t{c.Winvl[tw_lds_pos(i)]}; }
 };
 // The fp64 policy for digit lifts whose SOURCE limb may be above 2^52 (the 60-bit q0 of the reference's CKKS rings next to
 // its 40-bit primes, infer.jl:98-107): such a residue does not fit a double, so that digit is centred and reduced in

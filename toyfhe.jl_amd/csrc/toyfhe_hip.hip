@@ -83,7 +83,7 @@ int ensure_ws(tfhe_ctx* c, size_t bytes, void** out) {
             c->ws = nullptr;
             c->ws_bytes = 0;
         }
-        hipError_t e = hipMalloc(&c->ws, bytes);
+        hipError_t e = devalloc::malloc_retry(&c->ws, bytes);
         if (e != hipSuccess) return fail(TFHE_E_NOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         c->ws_bytes = bytes;
     }
@@ -357,6 +357,24 @@ int run_ntt_large(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t r
 }
 
 // forward / inverse transform of `rows` limb-polynomials; src == dst allowed
+// Per-limb routing masks are 32 bits wide (ntt_io_t::limb_mask, the key-switch kernels' limb_mask); TFHE_MAX_LIMBS is 40
+// and a special prime makes 41 working limbs, so rings with more than 32 selected limbs cannot be split by policy: they
+// run whole on the policy that takes every limb (all fp64-size / all narrow: the fast kernels unmasked; otherwise the
+// u64 / generic kernels unmasked).
+static inline u32 mask_all(int n) { return n >= 32 ? ~0u : ((1u << n) - 1u); }
+template <class F>
+static inline u32 mask_of(int n, F pred) {  // bit j set where pred(j); for n > 32: all-ones if pred holds everywhere, else 0
+    if (n > 32) {
+        for (int j = 0; j < n; j++)
+            if (!pred(j)) return 0u;
+        return ~0u;
+    }
+    u32 m = 0;
+    for (int j = 0; j < n; j++)
+        if (pred(j)) m |= 1u << j;
+    return m;
+}
+
 // `io` (optional) selects the fused global-I/O transforms of ntt_io_t; only for N <= 2^14 (single-block transforms)
 int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, const ntt_io_t* iop = nullptr) {
     if (rows == 0) return TFHE_OK;
@@ -369,11 +387,9 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
         const bool fp = sel_fp(c, sel, 0);
         // a ring that mixes fp64-size moduli with larger ones (60-bit q0 / special prime next to 40-bit primes): one launch
         // per policy, each taking its limbs (ntt_io_t::limb_mask)
-        u32 fpmask = 0;
-        for (int j = 0; j < sel.n; j++)
-            if (c->limbs_host[sel.idx[j]].Wd) fpmask |= 1u << j;
-        const u32 all = sel.n >= 32 ? ~0u : ((1u << sel.n) - 1u);
-        if (!fp && c->variant == 0 && fpmask != 0 && fpmask != all && (io.mode != 1 || n >= 12) && (rows << n) >= TFHE_MIXED_MIN_WORDS) {
+        const u32 fpmask = mask_of(sel.n, [&](int j) { return c->limbs_host[sel.idx[j]].Wd != nullptr; });
+        const u32 all = mask_all(sel.n);
+        if (!fp && c->variant == 0 && sel.n <= 32 && fpmask != 0 && fpmask != all && (io.mode != 1 || n >= 12) && (rows << n) >= TFHE_MIXED_MIN_WORDS) {
             // (digit-lift mode: the mask is on the TARGET limb j of item (b, i, j); the fp64 lift takes source limbs of either
             // size through ArithFpWide, instantiated for N >= 2^12)
             ntt_io_t a = io, b = io;
@@ -415,11 +431,9 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
     }
     // N > 2^14
     if (!iop && c->variant == 0) {
-        u32 fpmask = 0;
-        for (int j = 0; j < sel.n; j++)
-            if (c->limbs_host[sel.idx[j]].Wd) fpmask |= 1u << j;
-        const u32 all = sel.n >= 32 ? ~0u : ((1u << sel.n) - 1u);
-        if (fpmask != 0 && fpmask != all && (rows << n) >= TFHE_MIXED_MIN_WORDS) {  // mixed modulus sizes: one pass per policy, each over its limbs
+        const u32 fpmask = mask_of(sel.n, [&](int j) { return c->limbs_host[sel.idx[j]].Wd != nullptr; });
+        const u32 all = mask_all(sel.n);
+        if (sel.n <= 32 && fpmask != 0 && fpmask != all && (rows << n) >= TFHE_MIXED_MIN_WORDS) {  // mixed modulus sizes: one pass per policy, each over its limbs
             ntt_io_t a = io, b = io;
             a.limb_mask = fpmask;
             b.limb_mask = all & ~fpmask;
@@ -440,7 +454,7 @@ int launch_bfv_core_fused(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64
     *done = false;
     if (c->variant != 0 || c->logN != 14 || !sel_fp(c, sel, 0) || nct * sel.n > 0x7fffffffll) return TFHE_OK;
     constexpr int LOGT = logt_for(14);
-    const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
+    const size_t lds = fused_lds_bytes<14, LOGT, TFHE_TWL_CORE>();
     auto kern = k_bfv_core_fused<ArithFp, 14, LOGT>;
     static bool attr_set = false;
     if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
@@ -521,7 +535,7 @@ int tfhe_ctx_create(int64_t N, int L, const uint64_t* q, const uint64_t* psi, tf
     auto up = [&](const void* host, size_t bytes, const void** dev) -> bool {
         if (!host || !bytes) { *dev = nullptr; return true; }
         void* d = nullptr;
-        if (hipMalloc(&d, bytes) != hipSuccess) return false;
+        if (devalloc::malloc_retry(&d, bytes) != hipSuccess) return false;
         c->tabs.push_back(d);
         if (hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
         *dev = d;
@@ -546,7 +560,7 @@ int tfhe_ctx_create(int64_t N, int L, const uint64_t* q, const uint64_t* psi, tf
             return fail(TFHE_E_HIP, "allocating the twiddle tables failed (no usable HIP device?)");
         }
     }
-    if (hipMalloc(&c->limbs_dev, L * sizeof(ntt_limb_t)) != hipSuccess) { tfhe_ctx_destroy(c); return fail(TFHE_E_HIP, "hipMalloc failed"); }
+    if (devalloc::malloc_retry(&c->limbs_dev, L * sizeof(ntt_limb_t)) != hipSuccess) { tfhe_ctx_destroy(c); return fail(TFHE_E_HIP, "hipMalloc failed"); }
     hipMemcpy(c->limbs_dev, c->limbs_host.data(), L * sizeof(ntt_limb_t), hipMemcpyHostToDevice);
     if (hipStreamCreate(&c->stream) != hipSuccess) { tfhe_ctx_destroy(c); return fail(TFHE_E_HIP, "hipStreamCreate failed"); }
     {
@@ -582,9 +596,11 @@ int tfhe_ctx_psi(const tfhe_ctx* c, uint64_t* out) {
 int tfhe_ctx_set_stream(tfhe_ctx* c, void* s) {
     if (!c) return fail(TFHE_E_BADARG, "null context");
     if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
-    if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
-    else { HIP_TRY(hipStreamCreate(&c->stream)); c->own_stream = true; }
+    hipStream_t old = c->own_stream ? c->stream : nullptr, fresh = (hipStream_t)s;
+    if (!s) HIP_TRY(hipStreamCreate(&fresh));
+    devalloc::set_stream(&c->stream, fresh);                       // the allocator reads the slot under its mutex (tfhe_free)
+    c->own_stream = (s == nullptr);
+    if (old) hipStreamDestroy(old);
     return TFHE_OK;
 }
 int tfhe_ctx_sync(tfhe_ctx* c) {
@@ -853,11 +869,9 @@ static int ks_digits_fwd(tfhe_ctx* c, const ks_arg_t& A, const u64* ct, u64* dig
     // rings that mix fp64-size moduli with larger ones (infer.jl:97-112: 60-bit q0 and special prime next to 40-bit primes)
     // at N = 2^15 / 2^16: the fp64-size working limbs take the lift-fused one-kernel transforms (the fp64 lift reads source
     // limbs of either size), the others go through the digit buffer and the u64 kernels
-    u32 fpmask = 0;
-    for (int j = 0; j < nw; j++)
-        if (c->limbs_host[A.w.idx[j]].Wd) fpmask |= 1u << j;
-    const u32 allmask = (1u << nw) - 1u;
-    const bool lift_mixed = !lift_fused && (c->logN == 15 || c->logN == 16) && c->variant == 0 && fpmask != 0 && fpmask != allmask &&
+    const u32 fpmask = mask_of(nw, [&](int j) { return c->limbs_host[A.w.idx[j]].Wd != nullptr; });
+    const u32 allmask = mask_all(nw);
+    const bool lift_mixed = !lift_fused && nw <= 32 && (c->logN == 15 || c->logN == 16) && c->variant == 0 && fpmask != 0 && fpmask != allmask &&
                             (((uintptr_t)ct | (uintptr_t)dig) & 15u) == 0;
     if (lift_fused) {
         // digits: centred lift of limb i of c[end] into every working limb, fused into the forward NTT's loads
@@ -912,10 +926,10 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
     const unsigned gx = (n + 255) / 256;
     // enough workgroups to fill the chip: split the batch into slices (the key is re-read once per slice)
     const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx - 1) / (nw * gx)));
-    u32 nmask = 0;  // working limbs below 2^52: the two-coefficient, carry-free kernel; the others: the generic one
-    for (int j = 0; j < nw; j++)
-        if ((c->limbs_host[A.w.idx[j]].q >> 52) == 0) nmask |= 1u << j;
-    const u32 amask = (1u << nw) - 1u;
+    // working limbs below 2^52: the two-coefficient, carry-free kernel; the others: the generic one (more than 32 working
+    // limbs: all or nothing, see mask_of)
+    u32 nmask = mask_of(nw, [&](int j) { return (c->limbs_host[A.w.idx[j]].q >> 52) == 0; });
+    const u32 amask = mask_all(nw);
     if (n % 2 != 0) nmask = 0;
     if (nmask) {
         const unsigned gx2 = (n / 2 + 255) / 256;
@@ -946,9 +960,7 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
-    u32 fpm = 0;
-    for (int j = 0; j < nw; j++)
-        if (c->limbs_host[A.w.idx[j]].Wd) fpm |= 1u << j;
+    const u32 fpm = mask_of(nw, [&](int j) { return c->limbs_host[A.w.idx[j]].Wd != nullptr; });
     if (c->logN == 16 && c->variant == 0 && fpm != 0 && level >= 2 && (((uintptr_t)S | (uintptr_t)tbuf) & 15u) == 0) {
         // N = 2^16: the paired sub-block inverse into the (now free) digit buffer, then the two inverse top stages together with
         // the tail (k_ks_top_tail<2>) instead of k_ntt_inv_top<2> + k_ks_rescale_add / k_ks_add_ct.  Rings of mixed modulus sizes:
@@ -1013,7 +1025,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         const unsigned items = (unsigned)(batch * nw);
         if (c->logN == 14) {
             constexpr int LOGT = logt_for(14);
-            const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
+            const size_t lds = fused_lds_bytes<14, LOGT, TFHE_TWL_KS>();
             auto fk = prelifted ? k_ks_fused<ArithFp, 14, LOGT, true> : k_ks_fused<ArithFp, 14, LOGT, false>;
             static bool fattr_set = false;
             if (!fattr_set) {
@@ -1029,7 +1041,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         } else {  // N = 2^13: 256 threads x 32 elements, 65 KiB of LDS; 478 registers per thread, so one workgroup per CU is resident
                   // (capped to two resident workgroups it measured 5 % slower)
             constexpr int LOGT = logt_for(13);
-            const size_t lds = (size_t)lds_words<13, LOGT>() * 8;
+            const size_t lds = fused_lds_bytes<13, LOGT, TFHE_TWL_KS>();
             auto fk = k_ks_fused<ArithFp, 13, LOGT, false>;
             static bool fattr13_set = false;
             if (!fattr13_set) { rc = set_lds(fk, lds); if (rc) return rc; fattr13_set = true; }
@@ -1250,14 +1262,14 @@ static int ksw_table(tfhe_ctx* c, int level, const conv_tab_t** out) {
         *d = nullptr;
         if (v.empty()) return true;
         void* p = nullptr;
-        if (hipMalloc(&p, v.size() * 8) != hipSuccess) return false;
+        if (devalloc::malloc_retry(&p, v.size() * 8) != hipSuccess) return false;
         c->ksw_allocs.push_back(p);
         if (hipMemcpy(p, v.data(), v.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return false;
         *d = (const u64*)p;
         return true;
     };
     void* dt = nullptr;
-    if (!up(H.C, &T.C) || !up(H.M, &T.M) || !up(H.Aw, &T.Aw) || hipMalloc(&dt, sizeof T) != hipSuccess)
+    if (!up(H.C, &T.C) || !up(H.M, &T.M) || !up(H.Aw, &T.Aw) || devalloc::malloc_retry(&dt, sizeof T) != hipSuccess)
         return fail(TFHE_E_NOMEM, "allocating the window-digit tables failed");
     c->ksw_allocs.push_back(dt);
     HIP_TRY(hipMemcpy(dt, &T, sizeof T, hipMemcpyHostToDevice));
@@ -1266,22 +1278,26 @@ static int ksw_table(tfhe_ctx* c, int level, const conv_tab_t** out) {
     return TFHE_OK;
 }
 
-int tfhe_keyswitch_window(tfhe_ctx* c, int level, int window_bits, const uint64_t* evk, int n_windows, const uint64_t* ct, int polys,
-                          uint64_t* out, int64_t batch) {
+int tfhe_keyswitch_window(tfhe_ctx* c, int key_limbs, int level, int special, int window_bits, const uint64_t* evk, int n_windows,
+                          const uint64_t* ct, int polys, uint64_t* out, int64_t batch) {
     if (!c || !evk || !ct || !out) return fail(TFHE_E_BADARG, "null argument");
     if (polys != 2 && polys != 3) return fail(TFHE_E_BADARG, "keyswitch needs a 2- or 3-element ciphertext (rlwe_she.jl:318), got %d", polys);
-    if (level < 1 || level > c->L) return fail(TFHE_E_LEVEL_MISMATCH, "level=%d outside [1,%d]", level, c->L);
+    const int Lk = key_limbs;
+    if (Lk < 1 || Lk > c->L) return fail(TFHE_E_BADARG, "key_limbs=%d outside [1,%d]", Lk, c->L);
+    if (level < 1 || level > (special ? Lk - 1 : Lk)) return fail(TFHE_E_LEVEL_MISMATCH, "level=%d outside [1,%d]", level, special ? Lk - 1 : Lk);
     if (batch < 0) return fail(TFHE_E_BADARG, "negative batch");
     hostmath::bigint Q = hostmath::big_from(1);
-    u64 qmin = ~0ull;
+    u64 qmin = special ? c->q[Lk - 1] : ~0ull;
     for (int j = 0; j < level; j++) { Q = hostmath::big_mul_u64(Q, c->q[j]); qmin = std::min(qmin, c->q[j]); }
     if (window_bits < 1 || window_bits > 32 || (qmin >> window_bits) == 0)
         return fail(TFHE_E_BADARG, "window of %d bits: need 1 <= w <= 32 and 2^w below every modulus", window_bits);
     int qbits = 0;
     for (int w = (int)Q.size() - 1; w >= 0 && !qbits; w--)
         if (Q[w]) qbits = w * 64 + hostmath::bitlen(Q[w]);
-    const int need = (qbits + window_bits - 1) / window_bits;  // ndigits(Q, base = 2^w), rlwe_she.jl:333
-    if (n_windows != need)
+    // ndigits(modulus of the CIPHERTEXT ring, base = 2^w), rlwe_she.jl:333; a key made for a larger ring (a higher level, or the
+    // ModulusRaised key ring Q P, modulusraising.jl:28-32) has more components: the loop rlwe_she.jl:340 uses the first `need`
+    const int need = (qbits + window_bits - 1) / window_bits;
+    if (n_windows < need)
         return fail(TFHE_E_PARAMS_MISMATCH, "evaluation key has %d components, a %d-bit modulus in %d-bit windows has %d digits", n_windows, qbits, window_bits, need);
     if (batch == 0) return TFHE_OK;
     const conv_tab_t* T = nullptr;
@@ -1289,35 +1305,50 @@ int tfhe_keyswitch_window(tfhe_ctx* c, int level, int window_bits, const uint64_
     if (rc) return rc;
     const size_t N = (size_t)c->N;
     const u32 n = (u32)c->N;
-    const size_t per_ct = ((size_t)2 * level + (size_t)n_windows * level) * N * 8;
+    const int nw = special ? level + 1 : level;  // working limbs: [0 .. level-1] (+ the special prime, downswitch_keyelement modulusraising.jl:43-49)
+    const size_t per_ct = ((size_t)2 * nw + (size_t)need * nw) * N * 8;
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)((8192ull << 20) / per_ct)}));
-    const size_t ntt_tmp = c->logN > 14 ? (size_t)chunk * n_windows * level * N * 8 : 0;
+    const size_t ntt_tmp = c->logN > 14 ? (size_t)chunk * need * nw * N * 8 : 0;
     void* ws = nullptr;
     rc = ensure_ws(c, ntt_tmp + chunk * per_ct, &ws);
     if (rc) return rc;
     u64* S = (u64*)((char*)ws + ntt_tmp);
-    u64* dig = S + (size_t)chunk * 2 * level * N;
+    u64* dig = S + (size_t)chunk * 2 * nw * N;
     ks_arg_t A;   // inner product: `level` field = number of digits, nw = working limbs
     memset(&A, 0, sizeof A);
-    A.level = n_windows; A.nw = level; A.special = 0; A.polys = polys;
-    A.w.n = level;
+    A.level = need; A.nw = nw; A.special = special ? 1 : 0; A.polys = polys;
+    A.w.n = nw;
     for (int j = 0; j < level; j++) A.w.idx[j] = j;
-    ks_arg_t Al = A;  // row bookkeeping of the add kernel: `level` = limbs
+    if (special) A.w.idx[level] = Lk - 1;
+    ks_arg_t Al = A;  // row bookkeeping of the tail kernels: `level` = ciphertext limbs
     Al.level = level;
     const u32 add_s = polys == 3 ? 2u : 1u;
     const unsigned gx = (n + 255) / 256;
+    rescale_arg_t ra;
+    memset(&ra, 0, sizeof ra);
+    if (special) {
+        const u64 P = c->q[Lk - 1];
+        for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+    }
     for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
         const int64_t nb = std::min(chunk, batch - b0);
         const u64* cin = ct + (size_t)b0 * polys * level * N;
         u64* cout = out + (size_t)b0 * 2 * level * N;
-        hipLaunchKernelGGL(k_ks_window_digits, dim3((unsigned)(nb * gx)), dim3(256), 0, c->stream, cin, dig, T, level, window_bits, n_windows, polys, n, gx);
+        hipLaunchKernelGGL(k_ks_window_digits, dim3((unsigned)(nb * gx)), dim3(256), 0, c->stream, cin, dig, T, level, window_bits, need, polys, n, gx, nw);
         HIP_TRY(hipGetLastError());
-        rc = run_ntt(c, false, dig, dig, nb * n_windows * level, A.w);
+        rc = run_ntt(c, false, dig, dig, nb * need * nw, A.w);
         if (rc) return rc;
-        const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nb, (4096 + level * gx - 1) / (level * gx)));
-        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)level * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, level, n, (u32)nb, bsplit, 0u);
+        const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nb, (4096 + nw * gx - 1) / (nw * gx)));
+        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)nb, bsplit, 0u);
         HIP_TRY(hipGetLastError());
-        if (c->logN <= 14) {
+        if (special) {
+            // ModulusRaised: c1 = P c + S over [q_0 .. q_{level-1}, P], contracted by modswitch (modulusraising.jl:35-42):
+            // out_j = c_j + (T_j - [T_P]) P^-1 with T = INTT(S)  (the tail of the RNS-digit path, k_ks_rescale_add)
+            rc = run_ntt(c, true, S, S, nb * 2 * nw, A.w);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_ks_rescale_add, row_grid((unsigned)(nb * 2 * level), (size_t)c->N), dim3(256), 0, c->stream, S, cin, cout, c->limbs_dev, Al, ra, n, add_s);
+            HIP_TRY(hipGetLastError());
+        } else if (c->logN <= 14) {
             ntt_io_t io = io_plain();
             io.mode = 2; io.gsz = (u32)(2 * level); io.src_gstride = io.gsz; io.dst_gstride = io.gsz;
             io.add_rows = add_s * (u32)level; io.add_gstride = (u32)(polys * level); io.addend = cin;
@@ -1362,7 +1393,7 @@ static int ckks_tables(tfhe_ctx* c) {
         gpos[i] = brev((u32)(e >> 1));
     }
     auto up = [&](const void* h, size_t bytes, void** d) -> bool {
-        if (hipMalloc(d, bytes ? bytes : 8) != hipSuccess) return false;
+        if (devalloc::malloc_retry(d, bytes ? bytes : 8) != hipSuccess) return false;
         c->ksw_allocs.push_back(*d);
         return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };

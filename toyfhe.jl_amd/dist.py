@@ -33,6 +33,12 @@ def init(backend: str | None = None, device_id=None):
     return world, rank, local_rank
 
 
+def world_size_seen() -> int:
+    """ranks the process group actually has (1 without one): lets a bench line answer "did RCCL see N ranks"."""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

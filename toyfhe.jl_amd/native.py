@@ -119,7 +119,7 @@ def lib():
         "tfhe_galois": [vp, vp, vp, u64, i64, i32, i32p],
         "tfhe_keyswitch": [vp, i32, i32, i32, vp, i32, vp, i32, vp, i64],
         "tfhe_rotate": [vp, i32, i32, i32, vp, i32, u64, vp, vp, i64],
-        "tfhe_keyswitch_window": [vp, i32, i32, vp, i32, vp, i32, vp, i64],
+        "tfhe_keyswitch_window": [vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i64],
         "tfhe_rotate_many": [vp, i32, i32, i32, C.POINTER(vp), i32, i32, u64p, i32, vp, vp, i64],
         "tfhe_galois_key_prepare": [vp, i32, i32, u64, vp, vp],
         "tfhe_sample_uniform": [vp, i32, u64, C.c_uint32, u64, vp, i64],
@@ -320,8 +320,9 @@ class Context:
     def keyswitch(self, key_limbs, level, special, evk, n_digits, ct, polys, out, batch):
         check(lib().tfhe_keyswitch(self.h, key_limbs, level, int(bool(special)), evk, n_digits, ct, polys, out, batch))
 
-    def keyswitch_window(self, level, window_bits, evk, n_windows, ct, polys, out, batch):
-        check(lib().tfhe_keyswitch_window(self.h, level, window_bits, evk, n_windows, ct, polys, out, batch))
+    def keyswitch_window(self, level, window_bits, evk, n_windows, ct, polys, out, batch, key_limbs=None, special=False):
+        check(lib().tfhe_keyswitch_window(self.h, level if key_limbs is None else key_limbs, level, int(bool(special)), window_bits,
+                                          evk, n_windows, ct, polys, out, batch))
 
     def sample_uniform(self, level, seed, stream, first_poly, out, count):
         check(lib().tfhe_sample_uniform(self.h, level, int(seed), int(stream), int(first_poly), out, count))

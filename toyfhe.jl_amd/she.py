@@ -581,9 +581,7 @@ def make_eval_key(rng, old: RingElement, new: PrivKey) -> KeySwitchKey:
     params = new.params
     ring = old.ring
     if isinstance(params, ModulusRaised):
-        if params.relin_window != 0:
-            raise NotImplementedError("ModulusRaised with a digit window is not on the device path")
-        old = old * ring.moduli[-1]
+        old = old * ring.moduli[-1]                       # P * old over the key ring Q P; the gadget below is the parent's
     key = []
     if params.relin_window != 0:                          # base-2^w gadget, rlwe_she.jl:281-283
         w = params.relin_window
@@ -627,16 +625,24 @@ def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
     params = ek.params
     keyring = ek.key[0].mask.ring
     if params.relin_window != 0:                          # base-2^w digits, rlwe_she.jl:330-338
-        if isinstance(params, ModulusRaised):
-            raise NotImplementedError("ModulusRaised with a digit window is not on the device path")
+        special = isinstance(params, ModulusRaised)       # digits of c[end] over Q_level, keys over [q_0..q_{l-1}, P] (modulusraising.jl:35-49)
         ring, n, batch = c[0].ring, c[0].count, c[0].batch
-        if ring.idx != list(range(ring.L)) or keyring.idx != ring.idx:
-            raise UsageError("window key switch: key ring and ciphertext ring must be the same prefix of the context")
+        level = ring.L
+        if keyring.idx != list(range(keyring.L)) or ring.idx != list(range(level)) or level > keyring.L - (1 if special else 0):
+            raise UsageError("window key switch: the ciphertext ring must be a prefix of the key ring")
+        if ring.ctx is not keyring.ctx:
+            if ring.N != keyring.N or ring.moduli != keyring.moduli[:level] or ring.psi != keyring.psi[:level]:
+                raise UsageError("ciphertext and key belong to different rings")
+            keyring.ctx.wait_for(ring.ctx)
         cs = c.cs if _galois is None else [x.apply_galois_element(_galois) for x in c.cs]
-        ct = _pack([x.coeffs_primal() for x in cs], ring, n)
-        out = DeviceBuffer(n * 2 * ring.L * ring.N)
-        ring.ctx.keyswitch_window(ring.L, params.relin_window, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n)
-        return CipherText(c.params, _unpack(out, ring, n, 2, batch, primal=True), c.scale)
+        ct = _pack([x.coeffs_primal() for x in cs], ring, n, ctx=keyring.ctx)
+        out = DeviceBuffer(n * 2 * level * ring.N)
+        keyring.ctx.keyswitch_window(level, params.relin_window, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n,
+                                     key_limbs=keyring.L, special=special)
+        res = _unpack(out, ring, n, 2, batch, primal=True, ctx=keyring.ctx)
+        if ring.ctx is not keyring.ctx:
+            ring.ctx.wait_for(keyring.ctx)
+        return CipherText(c.params, res, c.scale)
     special = isinstance(params, ModulusRaised)
     ring, n, batch = c[0].ring, c[0].count, c[0].batch
     level = ring.L
@@ -653,7 +659,10 @@ def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
         keyring.ctx.keyswitch(keyring.L, level, special, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n)
     else:
         keyring.ctx.rotate(keyring.L, level, special, ek.packed().ptr, len(ek.key), _galois, ct.ptr, out.ptr, n)
-    return CipherText(c.params, _unpack(out, ring, n, 2, batch, primal=True, ctx=keyring.ctx), c.scale)
+    cs = _unpack(out, ring, n, 2, batch, primal=True, ctx=keyring.ctx)
+    if ring.ctx is not keyring.ctx:
+        ring.ctx.wait_for(keyring.ctx)                     # the results are elements of `ring`: its stream must see them written
+    return CipherText(c.params, cs, c.scale)
 
 
 def apply_galois_element(c: CipherText, g: int) -> CipherText:
@@ -696,6 +705,8 @@ def rotate_many(gks, c: CipherText):
     for r in range(len(gks)):
         view = _View(out, r * n * 2 * sz)
         res.append(CipherText(c.params, _unpack(view, ring, n, 2, batch, primal=True, ctx=keyring.ctx), c.scale))
+    if ring.ctx is not keyring.ctx:
+        ring.ctx.wait_for(keyring.ctx)                     # as in keyswitch: the results live on `ring`, written on the key ring's stream
     return res
 
 
