@@ -172,6 +172,7 @@ int emul_bfv(const uint64_t* qs, int ns, const uint64_t* pb, int nb, uint64_t t,
 }
 
 // fast (register-resident, folded) BFV expand / contract; returns -9 if (ns, np) has no instantiation
+// contract == 2: the narrow contraction on tensor rows given as reduced doubles (bit patterns), k_bfv_core_fused<.., OUTD>'s form
 int emul_bfv_fast(const uint64_t* qs, int ns, const uint64_t* pb, int nb, uint64_t t, int contract, int64_t N,
                   const uint64_t* src, uint64_t* dst, long count) {
     bfv_fast_host_t* H = new bfv_fast_host_t();
@@ -184,7 +185,7 @@ int emul_bfv_fast(const uint64_t* qs, int ns, const uint64_t* pb, int nb, uint64
             u64* d = contract ? dst + p * ns * N + k : dst + p * nb * N + k;
 #define FAST_(S, P_)                                                                           \
     else if (ns == S && np == P_) {                                                            \
-        if (H->tab.narrow) { u64 col[TFHE_FAST_MAX]; if (contract) bfv_contract_narrow<S, P_>(H->tab, s, N, d, N, col, 1); else bfv_expand_narrow<S, P_>(H->tab, s, N, d, N, col, 1); } \
+        if (H->tab.narrow) { u64 col[TFHE_FAST_MAX]; if (contract == 2) bfv_contract_narrow<S, P_, true>(H->tab, s, N, d, N, col, 1); else if (contract) bfv_contract_narrow<S, P_>(H->tab, s, N, d, N, col, 1); else bfv_expand_narrow<S, P_>(H->tab, s, N, d, N, col, 1); } \
         else { if (contract) bfv_contract_fast<S, P_, false>(H->tab, s, N, d, N); else bfv_expand_fast<S, P_, false>(H->tab, s, N, d, N); } \
     }
             if (false) {}

@@ -201,6 +201,16 @@ def test_bfv_fast_path_bodies(bits, ns, np_):
         for l, p in enumerate(pb):
             y[0, l, k] = (x * tinv) % big.Q % p
     assert np.array_equal(emul.bfv_fast(qs, pb, t, y, N, contract=True), ref_cpu.contract(cb, cs, t, y))
+    if bits <= 50:
+        # the same contraction on tensor rows handed over as reduced doubles (k_bfv_core_fused<.., OUTD> -> bfv_contract_narrow<.., TD>):
+        # centred representatives, and the two extreme lazy forms +-(p - 1)/2 -+ 1 a transform output may take
+        pbv = np.array(pb, dtype=np.int64).reshape(1, -1, 1)
+        yc = y.astype(np.int64)
+        yc = np.where(yc > pbv // 2, yc - pbv, yc)
+        yd = yc.astype(np.float64).view(np.uint64)
+        assert np.array_equal(emul.bfv_fast(qs, pb, t, yd, N, contract=2), ref_cpu.contract(cb, cs, t, y))
+        ylazy = np.where(yc == pbv // 2, yc - pbv, yc)                # p/2 -> -(p/2 + 1): the other representative at the edge
+        assert np.array_equal(emul.bfv_fast(qs, pb, t, ylazy.astype(np.float64).view(np.uint64), N, contract=2), ref_cpu.contract(cb, cs, t, y))
 
 
 

@@ -343,14 +343,29 @@ TFHE_HD u64 centred_double_bits(u64 r, u64 q) {
 // lifted_out: the residues are written as CENTRED DOUBLES (bit patterns) instead of canonical words -- the form the fused key
 // switch lifts its digit rows into (rlwe_she.jl:326-329); used for the c2 polynomial of a multiplication that is
 // relinearised next (internal buffer of tfhe_bfv_mul_relin only)
-template <int NS, int NP>
+// xi = (y a + b) mod p for a lazy double y, |y| <= p/2 + 1 (the reduced output of a transform)
+TFHE_HD double fp_affine_d(double y, double a, double b, double p, double pinv) {
+    double r = fp_reduce(fp_mulmod_c(y, ftw_t{a}, p, pinv) + b, p, pinv);
+    return r < 0.0 ? r + p : r;
+}
+// TD: the inputs are reduced doubles y (bit patterns, |y| <= p/2 + 1) instead of canonical words -- the form
+// k_bfv_core_fused<.., OUTD> leaves its result rows in.  ℛ-limbs go straight into the fp64 affine map; a P-limb enters its
+// product sum as the non-negative integer y + p (< 1.5 p + 1: within the 26-bit-split budget, and congruent).
+template <int NS, int NP, bool TD = false>
 TFHE_HD void bfv_contract_narrow(const bfv_fast_tab_t& B, const u64* src, size_t ls, u64* dst, size_t ld, u64* col, int cstride,
                                  bool lifted_out = false) {
     split26 xs[NS];
     double xd[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) {  // ξ_i of r = (t y + h) mod q
-        xd[i] = fp_affine(src[(size_t)B.pos_s[i] * ls], B.f_ca[i], B.f_cb[i], B.f_q[i], B.f_qinv[i]);
+        const u64 w = src[(size_t)B.pos_s[i] * ls];
+        if constexpr (TD) {
+            double y;
+            __builtin_memcpy(&y, &w, 8);
+            xd[i] = fp_affine_d(y, B.f_ca[i], B.f_cb[i], B.f_q[i], B.f_qinv[i]);
+        } else {
+            xd[i] = fp_affine(w, B.f_ca[i], B.f_cb[i], B.f_q[i], B.f_qinv[i]);
+        }
         xs[i] = split_of(fp_to_u64(xd[i]));
     }
     const u32 a1 = conv_alpha_fp<NS>(xd, xs, B.f_qinv, B.Mq, B.Aq, B.nwq, col, cstride);
@@ -360,7 +375,13 @@ TFHE_HD void bfv_contract_narrow(const bfv_fast_tab_t& B, const u64* src, size_t
 #pragma unroll
     for (int j = 0; j < NP; j++) {
         acc52 a{B.n_cB2[j], 0, 0};
-        acc52_macs(a, split_of(src[(size_t)B.pos_p[j] * ls]), B.n_cA2[j]);
+        u64 yp = src[(size_t)B.pos_p[j] * ls];
+        if constexpr (TD) {
+            double y;
+            __builtin_memcpy(&y, &yp, 8);
+            yp = fp_to_u64(y + B.f_p[j]);
+        }
+        acc52_macs(a, split_of(yp), B.n_cA2[j]);
 #pragma unroll
         for (int i = 0; i < NS; i++) acc52_macs(a, xs[i], B.t_cNegC1[j][i]);
         acc52_mac_small(a, a1, B.n_cA1[j]);

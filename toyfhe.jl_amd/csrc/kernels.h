@@ -50,7 +50,8 @@ __device__ __forceinline__ void fwd_schedule(u64* lds, const u64* gsrc, u64* gds
 // ---- inverse schedule with the twiddles of pass p+1 requested before the LDS exchange that ends pass p (8-byte fp64
 // twiddles: a whole pass's set fits the register budget of a 512-thread workgroup).  +9 % for the inverse transform; the
 // same idea measured slower for the forward one, which keeps the simple schedule. ----
-template <class A, int LOGB, int LOGT, int SEND, bool SCALE = true>
+// AO: the policy whose out_inv_* forms the words of the final store (ArithFpD: reduced doubles instead of canonical words)
+template <class A, int LOGB, int LOGT, int SEND, bool SCALE = true, class AO = A>
 __device__ __forceinline__ void inv_schedule_ptw(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
                                                  u32 pre, const u64* addend, const typename A::tw* tw_cur) {
     constexpr int K = pass_k_inv(LOGB, LOGT, SEND);
@@ -70,9 +71,9 @@ __device__ __forceinline__ void inv_schedule_ptw(u64* lds, const u64* gsrc, u64*
         if constexpr (S0 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S0 - K2, K2, false>(tw_next, C, tid, pre);
         inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid, nullptr);
         __syncthreads();
-        inv_schedule_ptw<A, LOGB, LOGT, S0, SCALE>(lds, gsrc, gdst, C, tid, pre, addend, tw_next);
+        inv_schedule_ptw<A, LOGB, LOGT, S0, SCALE, AO>(lds, gsrc, gdst, C, tid, pre, addend, tw_next);
     } else {
-        inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid, addend);
+        inv_store<AO, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid, addend);
     }
 }
 
@@ -1476,7 +1477,7 @@ __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, con
 // (+ addend) to gdst
 // SCALE = false: the caller has folded N^-1 into its operands (k_ks_fused: into the key rows), the last stage is a plain
 // butterfly instead of two scaling products per pair
-template <class A, int LOGB, int LOGT, bool SCALE = true, bool TWL = false>
+template <class A, int LOGB, int LOGT, bool SCALE = true, bool TWL = false, class AO = A>
 __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* v, u64* gdst, const typename A::ctx& C, const u64* addend) {
     constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB);
     constexpr int E = 1 << (LOGB - LOGT);
@@ -1496,7 +1497,7 @@ __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* 
         __syncthreads();
         ntt_inv_pass<ArithFpL, LOGB, LOGT, S1 - K2, K2, false, false, SCALE>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
         __syncthreads();
-        ntt_inv_pass<A, LOGB, LOGT, 0, S1 - K2, false, true, SCALE>(lds, nullptr, gdst, C, tid, 1u, 0, 0u, addend);
+        ntt_inv_pass<AO, LOGB, LOGT, 0, S1 - K2, false, true, SCALE>(lds, nullptr, gdst, C, tid, 1u, 0, 0u, addend);
     } else {
         typename A::tw tw_next[G2::SETS * G2::NTW];  // middle-pass twiddles, requested before the exchange
         {
@@ -1507,7 +1508,7 @@ __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* 
             inv_store<A, LOGB, LOGT, S1, KI1, true, SCALE>(v, lds, nullptr, C, tid);
         }
         __syncthreads();
-        inv_schedule_ptw<A, LOGB, LOGT, S1, SCALE>(lds, nullptr, gdst, C, tid, 1u, addend, tw_next);
+        inv_schedule_ptw<A, LOGB, LOGT, S1, SCALE, AO>(lds, nullptr, gdst, C, tid, 1u, addend, tw_next);
     }
 }
 
@@ -1789,7 +1790,8 @@ struct core_alt_t {  // limbs of ℛbig that are limbs of ℛ: read from the inp
     int ns;
     signed char idx[TFHE_MAX_LIMBS];  // limb j of ℛbig -> limb of ℛ, or -1
 };
-template <class A, int LOGB, int LOGT>
+// OUTD: the three result rows leave as reduced doubles (ArithFpD) for the narrow contraction (k_bfv_contract_fast<.., TD>)
+template <class A, int LOGB, int LOGT, bool OUTD = false>
 __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restrict__ Ea, const u64* __restrict__ Eb,
                                                                u64* __restrict__ T, u64* __restrict__ scratch,
                                                                const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems,
@@ -1799,6 +1801,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
     static_assert(pass_k_inv(LOGB, LOGT, LOGB) == K3, "forward last pass and inverse first pass must share the register map");
     typedef pgeom<LOGB, LOGT, LOGB - K3, K3> G3;
     constexpr int E = G3::E;
+    typedef typename std::conditional<OUTD, ArithFpD, A>::type AO;
     const u32 nb = (u32)sel.n;
     u64* const srow = scratch + ((size_t)blockIdx.x << LOGB);
     bool first = true;
@@ -1843,7 +1846,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
                     v[e] = fp_mulmod_c(v[e], ftw_t{A0[e]}, C.p, C.pinv);                                // a0 b0, in place
                 }
             }
-            fused_inv_from_regs<A, LOGB, LOGT, true, (TFHE_TWL_CORE & 2) != 0>(lds, v, t0, C, nullptr);
+            fused_inv_from_regs<A, LOGB, LOGT, true, (TFHE_TWL_CORE & 2) != 0, AO>(lds, v, t0, C, nullptr);
         }
         fused_fwd_to_regs<A, LOGB, LOGT, false, (TFHE_TWL_CORE & 1) != 0>(lds, pb1, C, first, v);
         {
@@ -1860,8 +1863,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_bfv_core_fused(const u64* __restr
                     A1[e] = fp_mulmod_c(v[e], ftw_t{A1[e]}, C.p, C.pinv);
                 }
             }
-            fused_inv_from_regs<A, LOGB, LOGT, true, (TFHE_TWL_CORE & 2) != 0>(lds, A0, t1, C, nullptr);
-            fused_inv_from_regs<A, LOGB, LOGT, true, (TFHE_TWL_CORE & 2) != 0>(lds, A1, t2, C, nullptr);
+            fused_inv_from_regs<A, LOGB, LOGT, true, (TFHE_TWL_CORE & 2) != 0, AO>(lds, A0, t1, C, nullptr);
+            fused_inv_from_regs<A, LOGB, LOGT, true, (TFHE_TWL_CORE & 2) != 0, AO>(lds, A1, t2, C, nullptr);
         }
     }
 }
@@ -2020,7 +2023,8 @@ __global__ __launch_bounds__(256) void k_bfv_expand_fast(const u64* __restrict__
 }
 // LIFT3 (narrow bodies, products: three polynomials per ciphertext): every third polynomial (c2) leaves as centred doubles
 // for the fused key switch (bfv_contract_narrow, lifted_out: workgroup-uniform).
-template <int NS, int NP, bool NARROW, bool LIFT3 = false>
+// TD (narrow bodies): the input rows are reduced doubles (k_bfv_core_fused<.., OUTD>) instead of canonical words
+template <int NS, int NP, bool NARROW, bool LIFT3 = false, bool TD = false>
 __global__ __launch_bounds__(256) void k_bfv_contract_fast(const u64* __restrict__ src, u64* __restrict__ dst,
                                                             const bfv_fast_tab_t* __restrict__ Bt, u32 n, u32 gx) {
     const u32 k = (blockIdx.x % gx) * 256 + threadIdx.x;
@@ -2029,7 +2033,7 @@ __global__ __launch_bounds__(256) void k_bfv_contract_fast(const u64* __restrict
     if (k >= n) return;
     if constexpr (NARROW) {
         __shared__ u64 col[(NS > NP ? NS : NP) * 256];  // scratch column of the rare exact-alpha decision (bfv_fast.h conv_alpha_fp)
-        bfv_contract_narrow<NS, NP>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n, col + threadIdx.x, 256, LIFT3 && b % 3u == 2u);
+        bfv_contract_narrow<NS, NP, TD>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n, col + threadIdx.x, 256, LIFT3 && b % 3u == 2u);
     } else {
         bfv_contract_fast<NS, NP, false>(*Bt, src + p * (NS + NP) * n + k, n, dst + p * NS * n + k, n);
     }

@@ -270,6 +270,13 @@ struct ArithFpL : ArithFp {
     static TFHE_HD tw ld_fwd(const ctx& c, u32 i) { return ftw_t{c.Wl[tw_lds_pos(i)]}; }
     static TFHE_HD tw ld_inv(const ctx& c, u32 i) { return ftw_t{c.Winvl[tw_lds_pos(i)]}; }
 };
+// ArithFp whose transform OUTPUT is the reduced lazy double (|r| <= p/2 + 1, as a bit pattern) instead of the canonical word:
+// three instructions per element instead of nine.  For the tensor rows between k_bfv_core_fused and the narrow contraction
+// (an internal buffer; the contraction's first step is an fp64 affine map anyway).
+struct ArithFpD : ArithFp {
+    static TFHE_HD u64 out_inv_scaled(elem v, const ctx& c) { return to_lds(fp_reduce(v, c.p, c.pinv)); }
+    static TFHE_HD u64 out_inv_lazy(elem v, const ctx& c) { return to_lds(fp_reduce(v, c.p, c.pinv)); }
+};
 // The fp64 policy for digit lifts whose SOURCE limb may be above 2^52 (the 60-bit q0 of the reference's CKKS rings next to
 // its 40-bit primes, infer.jl:98-107): such a residue does not fit a double, so that digit is centred and reduced in
 // integers (lift_digit) and enters as the centred double of its canonical residue; the choice is uniform over the item (one

@@ -450,14 +450,19 @@ bool bfv_core_fusable(const tfhe_ctx* c, const limb_sel_t& sel) { return c->vari
 // forward transforms + tensor + inverse transforms of one BFV multiplication chunk in one kernel (fp64 policy, N = 2^14);
 // *done = false when the configuration is not covered.  scratch: one row per workgroup.
 int launch_bfv_core_fused(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64* scratch, int64_t nct, const limb_sel_t& sel, bool* done,
-                          const core_alt_t* altp = nullptr) {
+                          const core_alt_t* altp = nullptr, bool out_double = false) {
     *done = false;
     if (c->variant != 0 || c->logN != 14 || !sel_fp(c, sel, 0) || nct * sel.n > 0x7fffffffll) return TFHE_OK;
     constexpr int LOGT = logt_for(14);
     const size_t lds = fused_lds_bytes<14, LOGT, TFHE_TWL_CORE>();
-    auto kern = k_bfv_core_fused<ArithFp, 14, LOGT>;
+    auto kern = out_double ? k_bfv_core_fused<ArithFp, 14, LOGT, true> : k_bfv_core_fused<ArithFp, 14, LOGT, false>;
     static bool attr_set = false;
-    if (!attr_set) { int rc = set_lds(kern, lds); if (rc) return rc; attr_set = true; }
+    if (!attr_set) {
+        int rc = set_lds(k_bfv_core_fused<ArithFp, 14, LOGT, true>, lds);
+        if (!rc) rc = set_lds(k_bfv_core_fused<ArithFp, 14, LOGT, false>, lds);
+        if (rc) return rc;
+        attr_set = true;
+    }
     const unsigned items = (unsigned)(nct * sel.n);
     const unsigned grid = std::min(items, (unsigned)c->num_cus);
     prof_begin(c, (int64_t)items * 7);  // limb transforms inside this launch: 4 forward + 3 inverse per item
