@@ -678,6 +678,44 @@ def test_full_size_bfv_mul_relin():
     assert np.array_equal(do2.to_numpy(got.shape), got[perm])
 
 
+@pytest.mark.parametrize("logn,ns,next_", [(12, 3, 4), (13, 3, 4), (13, 2, 3), (12, 6, 7)])
+def test_fused_bfv_core_at_the_reference_test_sizes(logn, ns, next_):
+    """k_bfv_core_fused at N = 2^12 and 2^13 (the sizes of the reference's own BFV tests and MNIST parameters: test/bfv_crt.jl:8,
+    infer.jl:97): 50-bit chains on the (ns, np) pairs of the register-resident conversions, more items than compute units,
+    ragged chunks -- against the oracle on picks across the chunk boundaries and against the one-operation-per-launch path
+    (NTT variant 3) on every ciphertext."""
+    N, t = 1 << logn, 65537
+    ch = H.chain(50, ns + next_, N)
+    qs = ch[:ns]
+    ctx = tf.Context(N, ch)
+    plan = tf.BfvPlan(ctx, ctx, t, idx_s=list(range(ns)))
+    rng = np.random.default_rng(1300 + logn + ns)
+    batch = 90                                                   # 90 * 7 = 630 items at (3, 4): more than 2 x 256 workgroups
+    c1, c2 = H.rand_residues(rng, qs, (batch, 2), N), H.rand_residues(rng, qs, (batch, 2), N)
+    evk = H.uniform_evk(rng, qs, ns, N)
+    d1, d2, devk = dev(c1), dev(c2), dev(evk)
+    do3 = tf.DeviceBuffer(batch * 3 * ns * N)
+    plan.set_chunk(64)
+    plan.mul(d1.ptr, d2.ptr, do3.ptr, batch)
+    got3 = do3.to_numpy((batch, 3, ns, N))
+    rs, rb = ref_cpu.RefCtx(N, qs), ref_cpu.RefCtx(N, ch)
+    pick = [0, 63, 64, batch - 1]
+    want3 = ref_cpu.bfv_mul(rs, rb, t, c1[pick], c2[pick])
+    assert np.array_equal(got3[pick], want3)
+    do = tf.DeviceBuffer(batch * 2 * ns * N)
+    plan.mul_relin(devk.ptr, ns, d1.ptr, d2.ptr, do.ptr, batch)
+    got = do.to_numpy((batch, 2, ns, N))
+    assert np.array_equal(got[pick], rs.keyswitch(ns, False, evk, want3))
+    ctx.set_ntt_variant(3)
+    do_b = tf.DeviceBuffer(batch * 3 * ns * N)
+    plan.mul(d1.ptr, d2.ptr, do_b.ptr, batch)
+    assert np.array_equal(do_b.to_numpy(got3.shape), got3)
+    do_c = tf.DeviceBuffer(batch * 2 * ns * N)
+    plan.mul_relin(devk.ptr, ns, d1.ptr, d2.ptr, do_c.ptr, batch)
+    ctx.set_ntt_variant(0)
+    assert np.array_equal(do_c.to_numpy(got.shape), got)
+
+
 def test_fused_pipeline_equals_three_kernel_pipeline():
     """BASELINE configuration with more (ciphertext, limb) items than compute units: the fused kernels (k_bfv_core_fused,
     k_ks_fused: several items per workgroup, ragged last chunk) against the separate transform / tensor / inner-product

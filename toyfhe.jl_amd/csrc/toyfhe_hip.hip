@@ -446,31 +446,45 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
 }
 
 
-bool bfv_core_fusable(const tfhe_ctx* c, const limb_sel_t& sel) { return c->variant == 0 && c->logN == 14 && sel_fp(c, sel, 0); }
-// forward transforms + tensor + inverse transforms of one BFV multiplication chunk in one kernel (fp64 policy, N = 2^14);
+bool bfv_core_fusable(const tfhe_ctx* c, const limb_sel_t& sel) { return c->variant == 0 && c->logN >= 12 && c->logN <= 14 && sel_fp(c, sel, 0); }
+// forward transforms + tensor + inverse transforms of one BFV multiplication chunk in one kernel (fp64 policy, N = 2^12 .. 2^14:
+// the reference's own BFV tests run at 2^11 - 2^12, test/bfv_crt.jl:8, and its MNIST parameters at 2^13, infer.jl:97);
 // *done = false when the configuration is not covered.  scratch: one row per workgroup.
-int launch_bfv_core_fused(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64* scratch, int64_t nct, const limb_sel_t& sel, bool* done,
-                          const core_alt_t* altp = nullptr, bool out_double = false) {
-    *done = false;
-    if (c->variant != 0 || c->logN != 14 || !sel_fp(c, sel, 0) || nct * sel.n > 0x7fffffffll) return TFHE_OK;
-    constexpr int LOGT = logt_for(14);
-    const size_t lds = fused_lds_bytes<14, LOGT, TFHE_TWL_CORE>();
-    auto kern = out_double ? k_bfv_core_fused<ArithFp, 14, LOGT, true> : k_bfv_core_fused<ArithFp, 14, LOGT, false>;
+template <int LOGB>
+static int launch_bfv_core_fused_n(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64* scratch, int64_t nct, const limb_sel_t& sel,
+                                   const core_alt_t& alt, bool out_double) {
+    constexpr int LOGT = logt_for(LOGB);
+    const size_t lds = fused_lds_bytes<LOGB, LOGT, TFHE_TWL_CORE>();
+    auto kern = out_double ? k_bfv_core_fused<ArithFp, LOGB, LOGT, true> : k_bfv_core_fused<ArithFp, LOGB, LOGT, false>;
     static bool attr_set = false;
     if (!attr_set) {
-        int rc = set_lds(k_bfv_core_fused<ArithFp, 14, LOGT, true>, lds);
-        if (!rc) rc = set_lds(k_bfv_core_fused<ArithFp, 14, LOGT, false>, lds);
+        int rc = set_lds(k_bfv_core_fused<ArithFp, LOGB, LOGT, true>, lds);
+        if (!rc) rc = set_lds(k_bfv_core_fused<ArithFp, LOGB, LOGT, false>, lds);
         if (rc) return rc;
         attr_set = true;
     }
     const unsigned items = (unsigned)(nct * sel.n);
-    const unsigned grid = std::min(items, (unsigned)c->num_cus);
+    // one 512-thread workgroup fills a CU at 2^14; the 256-thread workgroups of the smaller rings leave room for a second one
+    const unsigned grid = std::min(items, (LOGB == 14 ? 1u : 2u) * (unsigned)c->num_cus);
     prof_begin(c, (int64_t)items * 7);  // limb transforms inside this launch: 4 forward + 3 inverse per item
-    core_alt_t alt;
-    if (altp) alt = *altp; else { memset(&alt, 0, sizeof alt); alt.a = alt.b = nullptr; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, Ea, Eb, T, scratch, c->limbs_dev, sel, items, alt);
     prof_end(c);
     HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+int launch_bfv_core_fused(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64* scratch, int64_t nct, const limb_sel_t& sel, bool* done,
+                          const core_alt_t* altp = nullptr, bool out_double = false) {
+    *done = false;
+    if (!bfv_core_fusable(c, sel) || nct * sel.n > 0x7fffffffll) return TFHE_OK;
+    core_alt_t alt;
+    if (altp) alt = *altp; else { memset(&alt, 0, sizeof alt); alt.a = alt.b = nullptr; }
+    int rc;
+    switch (c->logN) {
+        case 12: rc = launch_bfv_core_fused_n<12>(c, Ea, Eb, T, scratch, nct, sel, alt, out_double); break;
+        case 13: rc = launch_bfv_core_fused_n<13>(c, Ea, Eb, T, scratch, nct, sel, alt, out_double); break;
+        default: rc = launch_bfv_core_fused_n<14>(c, Ea, Eb, T, scratch, nct, sel, alt, out_double); break;
+    }
+    if (rc) return rc;
     *done = true;
     return TFHE_OK;
 }
