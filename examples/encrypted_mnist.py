@@ -58,7 +58,7 @@ def plain_model(model, batch):
     return (plain_matmul(W2, sq2) + np.concatenate([model["fq2_b"], np.zeros(54)])[:, None])[:10]
 
 
-def encrypted_matmul(gk, W, x, B, cache=None):
+def encrypted_matmul(gk, W, x, B, cache=None, fused=False):
     """infer.jl:140-149: diagonal method; `rotate` by B slots moves every window's value to the next window.
     gk = one Galois key (the reference's loop: 63 chained rotations by B slots) or a list of 63 keys for the steps B, 2B, ...,
     63B (hoisted: every rotation starts from x and they share one digit decomposition, tfhe_rotate_many -- fewer transforms
@@ -79,6 +79,15 @@ def encrypted_matmul(gk, W, x, B, cache=None):
         pt.coeffs_dual()
         cache[key] = pt
         return pt
+    if isinstance(gk, (list, tuple)) and cache is not None and fused:
+        # the whole product in one device call (tfhe_matmul_diag): the diagonals are single plaintexts shared by the batch
+        key = (id(W), "fused", x.ring().L, x.scale)
+        if key not in cache:
+            vs = np.stack([np.repeat(np.array([W[i, (i - k) % n] for i in range(n)]), B) for k in range(n)]).astype(np.complex128)
+            enc = tf.ckks_encode(vs, x.ring(), x.scale)                       # the 64 diagonals as one stacked plaintext element
+            enc.coeffs_dual()
+            cache[key] = enc
+        return tf.matmul_diag(gk, cache[key], x)
     if isinstance(gk, (list, tuple)):
         rots = [x] + list(tf.rotate_many(gk, x))
     else:
@@ -104,7 +113,7 @@ def load_model(path=GOLDEN_MODEL):
     return m
 
 
-def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=False, repeat=1):
+def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=False, repeat=1, fused=False, return_logits=False):
     """`batches` = K ciphertext sets evaluated together (K * B images): every ring element carries a leading batch dimension
     of K, so each device call covers K ciphertexts (the batch the engine shards across GPUs)."""
     N = 1 << logn
@@ -146,25 +155,29 @@ def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=Fal
 
     fq1_blocks = [np.ascontiguousarray(model["fq1_w"][:, 64 * i:64 * (i + 1)]) for i in range(4)]   # stable ids for the cache
     W2 = np.vstack([model["fq2_w"], np.zeros((54, 64))])
-    cache = {} if repeat > 1 else None                            # pre-encoded weight plaintexts, filled by the first pass
+    cache = {} if (repeat > 1 or fused) else None                 # pre-encoded weight plaintexts, filled by the first pass
     for rep in range(repeat):
       t0 = time.perf_counter()
       conved = []
       for ch in range(4):
-          acc = None
-          for i in range(7):
-              for j in range(7):
-                  term = C[i][j].mul_plain(float(model["conv_w"][i, j, ch]))
-                  acc = term if acc is None else acc + term
+          if fused:    # the 49 scalar-weighted terms of a channel in one device pass per component (tfhe_lincomb)
+              acc = tf.CipherText.lincomb([C[i][j] for i in range(7) for j in range(7)],
+                                          [float(model["conv_w"][i, j, ch]) for i in range(7) for j in range(7)])
+          else:
+              acc = None
+              for i in range(7):
+                  for j in range(7):
+                      term = C[i][j].mul_plain(float(model["conv_w"][i, j, ch]))
+                      acc = term if acc is None else acc + term
           conved.append(tf.modswitch(acc.add_plain(float(model["conv_b"][ch]))))
       sq1 = [tf.modswitch(tf.keyswitch(ek, c * c)) for c in conved]
       fq1 = None
       for i in range(4):
-          part = encrypted_matmul(gk, fq1_blocks[i], sq1[i], B, cache)
+          part = encrypted_matmul(gk, fq1_blocks[i], sq1[i], B, cache, fused)
           fq1 = part if fq1 is None else fq1 + part
       fq1 = tf.modswitch(fq1.add_plain(np.repeat(model["fq1_b"], B)))
       sq2 = tf.modswitch(tf.keyswitch(ek, fq1 * fq1))
-      res = encrypted_matmul(gk, W2, sq2, B, cache).add_plain(np.repeat(np.concatenate([model["fq2_b"], np.zeros(54)]), B))
+      res = encrypted_matmul(gk, W2, sq2, B, cache, fused).add_plain(np.repeat(np.concatenate([model["fq2_b"], np.zeros(54)]), B))
       dec = tf.ckks_decode(tf.decrypt(kp, res), res.scale).real       # [K][N/2]
       got = dec.reshape(K, 64, B)[:, :10].transpose(1, 0, 2).reshape(10, K * B)
       t_eval = time.perf_counter() - t0
@@ -175,6 +188,8 @@ def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=Fal
               f"{'; pass ' + str(repeat) + ' with the weight plaintexts encoded by pass 1' if repeat > 1 else ''})")
         print(f"max |encrypted - plaintext| over the 10 x {K * B} logits: {err:.3e}   (logit range +-{np.abs(want).max():.2f})")
         print("argmax agreement:", float((got.argmax(0) == want.argmax(0)).mean()))
+    if return_logits:
+        return err, float(np.abs(want).max()), float((got.argmax(0) == want.argmax(0)).mean()), got
     return err, float(np.abs(want).max()), float((got.argmax(0) == want.argmax(0)).mean())
 
 
@@ -186,5 +201,7 @@ if __name__ == "__main__":
     ap.add_argument("--batches", type=int, default=1, help="ciphertext sets evaluated together (images = batches * N/128)")
     ap.add_argument("--hoisted", action="store_true", help="63 Galois keys and tfhe_rotate_many instead of 63 chained rotations")
     ap.add_argument("--repeat", type=int, default=1, help="evaluate this many times; from the second pass on the weight plaintexts are cached")
+    ap.add_argument("--fused", action="store_true",
+                    help="with --hoisted: each matrix product as one tfhe_matmul_diag call and each convolution channel as one tfhe_lincomb per component")
     a = ap.parse_args()
-    run(a.logn, a.seed, model=a.model, batches=a.batches, hoisted=a.hoisted, repeat=a.repeat)
+    run(a.logn, a.seed, model=a.model, batches=a.batches, hoisted=a.hoisted, repeat=a.repeat, fused=a.fused)

@@ -23,6 +23,10 @@
  *     of the fused key switch) that is recycled in stream order, so ONE host thread drives a given context at a time;
  *     different contexts / plans are independent and may be driven from different threads (no global mutable state
  *     besides the thread-local error text).  Share read-only inputs (evaluation keys, ciphertexts) freely.
+ *     tfhe_free, tfhe_ctx_destroy, tfhe_bfv_plan_destroy and tfhe_comm_destroy may be called from ANY thread (a garbage
+ *     collector's finalizer thread): tfhe_free takes the allocator's lock and parks the block behind events recorded on every
+ *     live context's stream -- it never waits and never touches a context's scratch; the destroy calls synchronise the
+ *     object's own stream first and must only not race with a call that is still USING that object.
  *   - a BFV plan over two contexts runs the extension-basis work on ℛbig's stream and the key switch on ℛ's stream and
  *     orders the two with events; it never re-points a context's stream.  Results are ordered on ℛ's stream
  *     (tfhe_ctx_sync(small) waits for them).
@@ -118,6 +122,13 @@ int tfhe_mad(tfhe_ctx *ctx, const uint64_t *acc, const uint64_t *a, const uint64
  * a, b: host arrays of n_terms device pointers.  Exact: the same canonical residues as tfhe_mad term by term. */
 int tfhe_dot(tfhe_ctx *ctx, const uint64_t *acc, const uint64_t *const *a, const uint64_t *const *b, int n_terms, uint64_t *dst,
              int64_t count, int limbs, const int32_t *limb_idx);
+/* dst = sum_{k < n_terms} scalars[k] * a[k], every a[k] and dst [count][limbs][N], either domain: the scalar-weighted sum of ring
+ * elements (per term one scalar_mul, pow2_cyc_rings.jl:177-185, and one +, :200-214) -- e.g. a convolution with plaintext
+ * scalar weights over encrypted inputs, examples/encrypted_mnist/infer.jl:127-129 (49 terms per channel and component) -- in
+ * one pass.  scalars: HOST array [n_terms][limbs] of residues (scalars[k][j] < modulus of limb j); a: host array of n_terms
+ * device pointers; n_terms <= 64.  Exact: the canonical residues of the term-by-term sum. */
+int tfhe_lincomb(tfhe_ctx *ctx, const uint64_t *scalars, const uint64_t *const *a, int n_terms, uint64_t *dst, int64_t count, int limbs,
+                 const int32_t *limb_idx);
 /* scalar_mul (pow2_cyc_rings.jl:177-185): scalar given as residues scal[j] mod q_{limb_idx[j]} (host array) */
 int tfhe_scalar_mul(tfhe_ctx *ctx, const uint64_t *scal, const uint64_t *a, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
 
@@ -158,6 +169,15 @@ int tfhe_rotate(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint
  *   ct: [batch][2][level][N]; out: [n_rot][batch][2][level][N]. */
 int tfhe_rotate_many(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint64_t *const *evks, int n_digits, int prepared,
                      const uint64_t *galois_elements, int n_rot, const uint64_t *ct, uint64_t *out, int64_t batch);
+/* Diagonal matrix-vector product in one call (examples/encrypted_mnist/infer.jl:140-149, test/ckks_matmul.jl:33-41):
+ *     out = diag[0] .* c + sum_{r < n_rot} diag[r+1] .* rotate(gk_r, c)
+ * with the rotations hoisted as in tfhe_rotate_many and every step run over all rotations at once; bit-identical to
+ * tfhe_rotate_many -> tfhe_nntt -> tfhe_dot.  evks: HOST array of n_rot device pointers to PREPARED Galois keys
+ * (tfhe_galois_key_prepare); galois_elements: HOST array [n_rot]; n_rot <= 64;
+ *   diags: device [n_rot + 1][level][N], the plaintext diagonals in the NTT domain at the ciphertext's level, shared by the batch;
+ *   ct: [batch][2][level][N] coefficient domain; out: [batch][2][level][N] NTT domain (the product's scale is the caller's business). */
+int tfhe_matmul_diag(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint64_t *const *evks, int n_digits,
+                     const uint64_t *galois_elements, int n_rot, const uint64_t *diags, const uint64_t *ct, uint64_t *out, int64_t batch);
 /* the one-time key preparation of the hoisted rotations: evk_out = the Galois key of x -> x^g (layout of tfhe_keyswitch,
  * n_digits components over key_limbs moduli) with every NTT-domain row permuted by g^-1, so that the key products run on the
  * transformed digits of the unrotated ciphertext.  prepared = 0 above takes plain keys and prepares them per call. */

@@ -191,3 +191,86 @@ def test_matmul_by_hoisted_rotations():
     got = tf.ckks_decode(tf.decrypt(kp, res), res.scale).real.reshape(n, B)
     want = W @ x.reshape(n, B)
     assert np.allclose(got, want, atol=1e-5)
+
+
+@pytest.mark.parametrize("logn,bits,n_rot,batch", [(6, [40, 40, 40, 40], 7, None), (12, [60, 40, 40, 60], 5, 3), (14, [50, 50, 50, 50], 4, 2),
+                                                   (15, [40, 40, 40, 40], 3, 2), (16, [60, 40, 40, 40, 60], 3, 2)])
+def test_matmul_diag_is_bit_identical_to_rotate_many_and_dot(logn, bits, n_rot, batch):
+    """tfhe_matmul_diag (every step of the hoisted diagonal product run over all rotations at once) against the composition it
+    replaces -- rotate_many, the forward transforms and CipherText.dot_plain -- word for word, on uniform rings, on the
+    reference's mixed 60/40-bit CKKS rings (infer.jl:97-112) and through the sub-block transforms of N = 2^15 / 2^16; the
+    diagonals given as a list of plaintext elements and as one stacked element."""
+    N = 1 << logn
+    qs, used = [], set()
+    for b in bits:
+        q = tf.nextprime(2**b + 1, 1, 2 * N)
+        while q in used:
+            q = tf.nextprime(q + 2 * N, 1, 2 * N)
+        used.add(q); qs.append(q)
+    R = tf.NegacyclicRing(N, qs)
+    params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    rng = tf.DeviceRng(1000 + logn)
+    kp = tf.keygen(rng, params)
+    scale = 2**30
+    nrng = np.random.default_rng(logn)
+    shape = (N // 2,) if batch is None else (batch, N // 2)
+    x = nrng.normal(0, 1, shape).astype(complex)
+    c = tf.encrypt(rng, kp, tf.ckks_encode(x, params.R_cipher(), scale), scale=scale)
+    gks = [tf.keygen_galois(rng, kp.priv, steps=k) for k in range(1, n_rot + 1)]
+    dv = nrng.normal(0, 1, (n_rot + 1, N // 2)).astype(complex)
+    stacked = tf.ckks_encode(dv, params.R_cipher(), scale)
+    singles = [tf.ckks_encode(dv[k], params.R_cipher(), scale) for k in range(n_rot + 1)]
+    rots = tf.rotate_many(gks, c)
+    bcast = [d if batch is None else d.broadcast_to(batch) for d in singles]
+    want = tf.CipherText.dot_plain([c] + list(rots), bcast)
+    for diags in (singles, stacked):
+        got = tf.matmul_diag(gks, diags, c)
+        assert got.scale == want.scale and len(got) == 2
+        for a, b in zip(got.cs, want.cs):
+            assert a.primal is None                                             # NTT-domain result, like dot_plain's
+            assert np.array_equal(a.to_numpy("dual"), b.to_numpy("dual"))
+    dec = tf.ckks_decode(tf.decrypt(kp, got), got.scale)
+    ref = dv[0] * x + sum(dv[k] * np.roll(x, k, axis=-1) for k in range(1, n_rot + 1))
+    assert np.abs(dec - ref).max() < (1e-4 if logn < 10 else 5e-2)             # scale 2^30: fresh noise ~ sqrt(N) sigma / 2^30 per term
+    # a lower level of the same keys (downswitch_keyelement, modulusraising.jl:43-49) and no rotation at all
+    lo = tf.modswitch(c)
+    dl = tf.ckks_encode(dv, lo.ring(), lo.scale)
+    got = tf.matmul_diag(gks, dl, lo)
+    want = tf.CipherText.dot_plain([lo] + list(tf.rotate_many(gks, lo)), [tf.ckks_encode(dv[k], lo.ring(), lo.scale) if batch is None else
+                                                                          tf.ckks_encode(dv[k], lo.ring(), lo.scale).broadcast_to(batch) for k in range(n_rot + 1)])
+    assert all(np.array_equal(a.to_numpy("dual"), b.to_numpy("dual")) for a, b in zip(got.cs, want.cs))
+    only = tf.matmul_diag([], [singles[0]], c)
+    w0 = c.mul_plain(singles[0] if batch is None else singles[0].broadcast_to(batch))
+    assert all(np.array_equal(a.to_numpy("dual"), b.to_numpy("dual")) for a, b in zip(only.cs, w0.cs))
+
+
+def test_lincomb_equals_the_sum_of_scalar_products():
+    """CipherText.lincomb (tfhe_lincomb: the 49 scalar-weighted terms of a convolution channel, infer.jl:127-129, in one pass per
+    component) against sum(c.mul_plain(w)) word for word, in both domains, single and batched."""
+    N = 256
+    R = tf.NegacyclicRing(N, chain(2**40 + 1, 2, N) + [tf.nextprime(2**60 + 1, 1, 2 * N)])
+    params = tf.CKKSParams(R, 0, 3.2)
+    rng = tf.DeviceRng(77)
+    kp = tf.keygen(rng, params)
+    scale = 2**40
+    nrng = np.random.default_rng(5)
+    for batch in (None, 3):
+        shape = (N // 2,) if batch is None else (batch, N // 2)
+        cts = [tf.encrypt(rng, kp, tf.ckks_encode(nrng.normal(0, 1, shape).astype(complex), R, scale), scale=scale) for _ in range(49)]
+        ws = list(nrng.normal(0, 0.2, 47)) + [0.0, -1.5]
+        want = None
+        for c, w in zip(cts, ws):
+            t = c.mul_plain(float(w))
+            want = t if want is None else want + t
+        got = tf.CipherText.lincomb(cts, ws)
+        assert got.scale == want.scale
+        for a, b in zip(got.cs, want.cs):
+            assert np.array_equal(a.to_numpy(), b.to_numpy())
+        for c in cts:                                                           # NTT-domain operands
+            for x in c.cs:
+                x.coeffs_dual(); x.primal = None
+        got = tf.CipherText.lincomb(cts, ws)
+        for a, b in zip(got.cs, want.cs):
+            assert a.primal is None and np.array_equal(a.to_numpy("dual"), b.to_numpy("dual"))
+    with pytest.raises(AssertionError):
+        tf.CipherText.lincomb(cts, ws[:-1])

@@ -402,6 +402,16 @@ def test_encrypted_mnist_with_hoisted_rotations():
     assert err2 < 1e-3 and agree2 == 1.0, (err2, agree2)
 
 
+def test_encrypted_mnist_fused_calls_give_the_same_logits_to_the_last_bit():
+    """the pipeline with one tfhe_matmul_diag call per matrix product and one tfhe_lincomb per convolution channel and component
+    (`--hoisted --fused`) against the hoisted path it replaces: identical ciphertext arithmetic, so the decrypted logits are equal
+    as doubles."""
+    a = _mnist().run(logn=13, seed=1, verbose=False, model="reference", batches=2, hoisted=True, repeat=2, return_logits=True)
+    b = _mnist().run(logn=13, seed=1, verbose=False, model="reference", batches=2, hoisted=True, fused=True, return_logits=True)
+    assert b[0] < 1e-3 and b[2] == 1.0
+    assert np.array_equal(a[3], b[3])
+
+
 def test_encrypted_mnist_reference_model_at_2_16():
     """BASELINE config #5 as stated (N = 2^16, 512 images per ciphertext) on the same model and moduli chain; the reference's
     floor rescale leaves a bias that grows with N (see test_cfg3_ckks_rotate_decrypts_at_full_degree), hence the looser bound."""

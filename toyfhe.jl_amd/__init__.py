@@ -11,4 +11,4 @@ from .ring import NegacyclicRing, RingElement, nextprime  # noqa: F401,E402
 from . import wire  # noqa: F401,E402
 from .she import (DeviceRng, BFVParams, BGVParams, CKKSParams, CipherText, ModulusRaised, apply_galois_element,  # noqa: F401,E402
                   ckks_decode, ckks_encode, decrypt, enc_mul, encrypt, invariant_noise_budget, keygen, keygen_evalmult, keygen_galois,
-                  keyswitch, make_eval_key, modswitch, rotate, rotate_many)
+                  keyswitch, make_eval_key, matmul_diag, modswitch, rotate, rotate_many)

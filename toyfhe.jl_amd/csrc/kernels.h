@@ -1110,6 +1110,57 @@ __global__ __launch_bounds__(256) void k_dot(dot_arg_t D, const u64* __restrict_
     }
 }
 
+// dst[row] = sum_k scal[k][j] * a_k[row] (limb-wise, either domain): the scalar-weighted sum of ring elements behind a
+// convolution with plaintext scalar weights (infer.jl:127-129: 49 ciphertexts times 49 scalars per channel -- per term one
+// scalar_mul pow2_cyc_rings.jl:177-185 and one + :200-214).  scal: device array [K][limbs], residues of the scalars.
+__global__ __launch_bounds__(256) void k_lincomb(dot_arg_t D, const u64* __restrict__ scal, u64* __restrict__ dst,
+                                                  const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 n) {
+    const u32 row = blockIdx.x, j = row % (u32)sel.n;
+    const ntt_limb_t L = LT[sel.idx[j]];
+    const size_t base = (size_t)row * n;
+    int bits = 0;
+    while ((L.q >> bits) != 0) bits++;
+    const int chunk = bits >= 62 ? 1 : (62 - bits >= 6 ? 64 : (1 << (62 - bits)));   // products summed between two reductions
+    for (u32 i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
+        u64 r = 0;
+        for (int k0 = 0; k0 < D.n; k0 += chunk) {
+            acc128 s{r, 0};
+            const int k1 = k0 + chunk < D.n ? k0 + chunk : D.n;
+            for (int k = k0; k < k1; k++) acc_mac(s, D.a[k][base + i], scal[(size_t)k * sel.n + j]);
+            r = barrett_reduce128(s.lo, s.hi, L.br);
+        }
+        dst[base + i] = r;
+    }
+}
+
+// Diagonal matrix-vector product, accumulation step: out[b][s][j] = diag[0][j] (.) X[b][s][j] + sum_r diag[r+1][j] (.) ROT[r][b][s][j]
+// (NTT domain; the loop `result += rotated_k * diagonal_k` of infer.jl:140-149 / test/ckks_matmul.jl:33-41 over all terms in
+// one pass: the canonical residues of the term-by-term sum).  diag: [R+1][limbs][N], shared by the batch.
+__global__ __launch_bounds__(256) void k_matmul_acc(const u64* __restrict__ X, const u64* __restrict__ ROT, const u64* __restrict__ diag,
+                                                     u64* __restrict__ out, const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 n,
+                                                     u32 nrot, u32 rows_per_rot) {
+    const u32 row = blockIdx.x, j = row % (u32)sel.n;   // row = (b * 2 + s) * limbs + j
+    const ntt_limb_t L = LT[sel.idx[j]];
+    const size_t base = (size_t)row * n, rstride = (size_t)rows_per_rot * n, dstride = (size_t)sel.n * n;
+    const u64* dj = diag + (size_t)j * n;
+    int bits = 0;
+    while ((L.q >> bits) != 0) bits++;
+    const u32 chunk = bits >= 62 ? 1u : (62 - bits >= 6 ? 64u : (1u << (62 - bits)));
+    for (u32 i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
+        u64 r = 0;
+        for (u32 k0 = 0; k0 <= nrot; k0 += chunk) {
+            acc128 s{r, 0};
+            const u32 k1 = k0 + chunk <= nrot ? k0 + chunk : nrot + 1;
+            for (u32 k = k0; k < k1; k++) {
+                const u64 x = k == 0 ? X[base + i] : ROT[(size_t)(k - 1) * rstride + base + i];
+                acc_mac(s, x, dj[(size_t)k * dstride + i]);
+            }
+            r = barrett_reduce128(s.lo, s.hi, L.br);
+        }
+        out[base + i] = r;
+    }
+}
+
 // tensor (rlwe_she.jl:255-258) in the NTT domain: a,b [batch][2][limbs][N] -> out [batch][3][limbs][N]
 __global__ __launch_bounds__(256) void k_tensor(const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out,
                                                  const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 n) {
@@ -1925,6 +1976,46 @@ __global__ __launch_bounds__(256) void k_ks_rescale_add(const u64* __restrict__ 
         u64 v = shoup_full(submod(tj[k], last, L.q), ra.qlinv[j], L.q);
         if (c) v = addmod(v, c[k], L.q);
         o[k] = v;
+    }
+}
+
+// Hoisted rotations, the tail for ALL rotations of a diagonal product in one launch: T = INTT(S') [R][batch][2][nw][N] holds the
+// inverse-transformed key sums of the unrotated digits; rotation r's result is sigma_g( . ) applied per limb in the coefficient
+// domain (a signed permutation, BEFORE the floor of the ModulusRaised contraction, which does not commute with sign changes;
+// see ks_finish), then out_j = sigma_g(c)_j + (T'_j - [T'_P]) P^-1 (special) or sigma_g(c)_j + T'_j, for s = 0 only the addend.
+// Gather form: output coefficient m takes source coefficient i0 = m g^-1 mod 2N (sign = i0 >= N).  out: [R][batch][2][level][N].
+struct rot_tail_arg_t {
+    u64 ginv[TFHE_DOT_MAX];
+};
+__global__ __launch_bounds__(256) void k_ks_rot_tail(const u64* __restrict__ T, const u64* __restrict__ ct, u64* __restrict__ out,
+                                                      const ntt_limb_t* __restrict__ LT, ks_arg_t A, rescale_arg_t ra, rot_tail_arg_t G,
+                                                      u32 n, u32 batch) {
+    const u32 level = (u32)A.level, nw = (u32)A.nw;
+    const u32 row = blockIdx.x, j = row % level, s = (row / level) & 1u, b = (row / (2u * level)) % batch, r = row / (2u * level * batch);
+    const ntt_limb_t L = LT[A.w.idx[j]];
+    const u64 P = A.special ? LT[A.w.idx[level]].q : 0;
+    const u64* tj = T + ((((size_t)r * batch + b) * 2 + s) * nw + j) * n;
+    const u64* tl = T + ((((size_t)r * batch + b) * 2 + s) * nw + level) * n;
+    const u64* c = s == 0 ? ct + (((size_t)b * 2 + 0) * level + j) * n : nullptr;   // 2-element input: only c_1 has an addend (rlwe_she.jl:324)
+    u64* o = out + (size_t)row * n;
+    const u64 ginv = G.ginv[r], mask2n = 2ull * n - 1;
+    for (u32 m = blockIdx.y * blockDim.x + threadIdx.x; m < n; m += gridDim.y * blockDim.x) {
+        const u64 i0 = ((u64)m * ginv) & mask2n;
+        const u32 i = (u32)(i0 & (n - 1));
+        const bool neg = i0 >= n;
+        u64 v = tj[i];
+        if (neg) v = negmod(v, L.q);
+        if (A.special) {
+            u64 last = tl[i];
+            if (neg) last = negmod(last, P);
+            v = shoup_full(submod(v, barrett_reduce128(last, 0, L.br), L.q), ra.qlinv[j], L.q);
+        }
+        if (c) {
+            u64 a = c[i];
+            if (neg) a = negmod(a, L.q);
+            v = addmod(v, a, L.q);
+        }
+        o[m] = v;
     }
 }
 

@@ -770,6 +770,45 @@ int tfhe_dot(tfhe_ctx* c, const uint64_t* acc, const uint64_t* const* a, const u
     return TFHE_OK;
 }
 
+int tfhe_lincomb(tfhe_ctx* c, const uint64_t* scalars, const uint64_t* const* a, int n_terms, uint64_t* dst, int64_t count, int limbs,
+                 const int32_t* idx) {
+    if (!c || !scalars || !a || !dst) return fail(TFHE_E_BADARG, "null argument");
+    if (n_terms < 1) return fail(TFHE_E_BADARG, "tfhe_lincomb needs at least one term");
+    limb_sel_t sel;
+    int rc = make_sel(c, limbs, idx, &sel);
+    if (rc) return rc;
+    if (count < 0) return fail(TFHE_E_BADARG, "negative count");
+    if (count == 0) return TFHE_OK;
+    for (int k = 0; k < n_terms; k++)
+        if (!a[k]) return fail(TFHE_E_BADARG, "null operand %d", k);
+    std::vector<u64> sc((size_t)n_terms * limbs);
+    for (int k = 0; k < n_terms; k++)
+        for (int j = 0; j < limbs; j++) {
+            const u64 q = c->q[sel.idx[j]], v = scalars[(size_t)k * limbs + j];
+            if (v >= q) return fail(TFHE_E_BADARG, "scalar %d, limb %d is not a residue", k, j);
+            sc[(size_t)k * limbs + j] = v;
+        }
+    void* dsc = nullptr;
+    hipError_t e = devalloc::alloc(sc.size() * 8, &dsc);
+    if (e != hipSuccess) return fail(TFHE_E_NOMEM, "hipMalloc(%zu): %s", sc.size() * 8, hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(dsc, sc.data(), sc.size() * 8, hipMemcpyHostToDevice, c->stream));   // pageable source: staged before the call returns
+    u64* tmp = nullptr;  // more than 64 terms: partial sums are added up by a second pass of the same kernel with unit scalars
+    const int nchunks = (n_terms + TFHE_DOT_MAX - 1) / TFHE_DOT_MAX;
+    if (nchunks > 1) {
+        devalloc::release(dsc);
+        return fail(TFHE_E_UNSUPPORTED, "tfhe_lincomb takes at most %d terms per call", TFHE_DOT_MAX);
+    }
+    (void)tmp;
+    dot_arg_t D;
+    D.n = n_terms;
+    for (int k = 0; k < n_terms; k++) { D.a[k] = a[k]; D.b[k] = nullptr; }
+    hipLaunchKernelGGL(k_lincomb, row_grid((unsigned)(count * limbs), (size_t)c->N), dim3(256), 0, c->stream, D, (const u64*)dsc, dst, c->limbs_dev, sel, (u32)c->N);
+    hipError_t le = hipGetLastError();
+    devalloc::release(dsc);   // parked until the launch above has run
+    if (le != hipSuccess) return fail(TFHE_E_HIP, "k_lincomb: %s", hipGetErrorString(le));
+    return TFHE_OK;
+}
+
 int tfhe_tensor(tfhe_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, int64_t batch, int limbs, const int32_t* idx) {
     if (!c || !a || !b || !out) return fail(TFHE_E_BADARG, "null argument");
     limb_sel_t sel;
@@ -929,19 +968,10 @@ static int ks_digits_fwd(tfhe_ctx* c, const ks_arg_t& A, const u64* ct, u64* dig
 }
 
 static int do_galois(tfhe_ctx* c, const u64* src, u64* dst, u64 g, int64_t rows, const limb_sel_t& sel);
-// Part B: S_s = sum_i evk_{i,s} (.) digit_i, inverse transforms, and the tail out_s = ct_s + ... (with the special prime: the
-// ModulusRaised contraction).  `ct` only supplies the addends.  `tbuf` ([batch][2][nw][N]) receives the sub-block inverse at
-// N = 2^16; the plain key switch passes the digit buffer (free by then).
-// Hoisted rotations (g != 0): `evk` is the key of x -> x^g prepared by tfhe_galois_key_prepare (its NTT-domain rows permuted by
-// g^-1), so the sums are those of the rotated digits up to that permutation: S' = sigma_g^-1(S).  The automorphism is applied
-// to INTT(S') in the coefficient domain (a signed permutation) BEFORE the tail -- the ModulusRaised floor does not commute
-// with sign changes -- into `tbuf`, which must not alias the digits (they are reused by the next rotation).
-static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, const u64* ct, u64* out, int64_t batch, u64* S,
-                     const u64* dig, u64* tbuf, u64 g) {
-    const int level = A.level, nw = A.nw, polys = A.polys, special = A.special;
+// S_s = sum_i evk_{i,s} (.) digit_i over the working limbs (NTT domain), S: [batch][2][nw][N]
+static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, const u64* dig, u64* S, int64_t batch) {
+    const int nw = A.nw;
     const u32 n = (u32)c->N;
-    const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
-    int rc;
     const unsigned gx = (n + 255) / 256;
     // enough workgroups to fill the chip: split the batch into slices (the key is re-read once per slice)
     const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx - 1) / (nw * gx)));
@@ -961,6 +991,26 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
                            nmask ? (amask & ~nmask) : 0u);
     }
     HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+// Part B: S_s = sum_i evk_{i,s} (.) digit_i, inverse transforms, and the tail out_s = ct_s + ... (with the special prime: the
+// ModulusRaised contraction).  `ct` only supplies the addends.  `tbuf` ([batch][2][nw][N]) receives the sub-block inverse at
+// N = 2^16; the plain key switch passes the digit buffer (free by then).
+// Hoisted rotations (g != 0): `evk` is the key of x -> x^g prepared by tfhe_galois_key_prepare (its NTT-domain rows permuted by
+// g^-1), so the sums are those of the rotated digits up to that permutation: S' = sigma_g^-1(S).  The automorphism is applied
+// to INTT(S') in the coefficient domain (a signed permutation) BEFORE the tail -- the ModulusRaised floor does not commute
+// with sign changes -- into `tbuf`, which must not alias the digits (they are reused by the next rotation).
+static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, const u64* ct, u64* out, int64_t batch, u64* S,
+                     const u64* dig, u64* tbuf, u64 g) {
+    const int level = A.level, nw = A.nw, polys = A.polys, special = A.special;
+    const u32 n = (u32)c->N;
+    const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
+    int rc;
+    const unsigned gx = (n + 255) / 256;
+    rc = ks_inner_launch(c, A, Lk, evk, dig, S, batch);
+    if (rc) return rc;
+    const u32 amask = mask_all(nw);
+    (void)gx;
     if (g != 0) {  // hoisted rotation: INTT, automorphism, tail
         rc = run_ntt(c, true, S, S, batch * 2 * nw, A.w);
         if (rc) return rc;
@@ -1265,6 +1315,90 @@ int tfhe_rotate(tfhe_ctx* c, int Lk, int level, int special, const uint64_t* evk
     if (rc) return rc;
     if ((g & 1) == 0) return fail(TFHE_E_BADARG, "galois element must be odd");
     return keyswitch_impl(c, Lk, level, special, evk, ct, 2, out, batch, g, true);
+}
+
+// ---- diagonal matrix-vector product (infer.jl:140-149, test/ckks_matmul.jl:33-41) in one call ---------------------------
+// out = diag_0 (.) c + sum_r diag_{r+1} (.) rotate(gk_r, c): the hoisted rotations of tfhe_rotate_many (one digit decomposition
+// of c) with every step -- key sums, inverse transforms, automorphism + tail, forward transforms, accumulation -- run over ALL
+// rotations at once instead of rotation by rotation (R x more rows per launch: about 15 launches per product instead of
+// about 8 R + 2 R + 2), and the rotated ciphertexts never return to the caller.  Same arithmetic, term by term, as
+// rotate_many -> nntt -> dot: bit-identical results.
+int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t* const* evks, int n_digits, const uint64_t* galois,
+                     int n_rot, const uint64_t* diags, const uint64_t* ct, uint64_t* out, int64_t batch) {
+    if (!evks || !galois || !diags || n_rot < 0) return fail(TFHE_E_BADARG, "null argument");
+    if (n_rot > TFHE_DOT_MAX) return fail(TFHE_E_UNSUPPORTED, "tfhe_matmul_diag takes at most %d rotations per call", TFHE_DOT_MAX);
+    for (int r = 0; r < n_rot; r++) {
+        int rc = ks_check(c, Lk, level, special, evks[r], n_digits, ct, 2, out, batch);
+        if (rc) return rc;
+        if ((galois[r] & 1) == 0 || galois[r] >= 2 * (u64)c->N) return fail(TFHE_E_BADARG, "galois element must be odd and below 2N");
+    }
+    if (n_rot == 0) {
+        int rc = ks_check(c, Lk, level, special, diags, n_digits, ct, 2, out, batch);
+        if (rc) return rc;
+    }
+    if (batch == 0) return TFHE_OK;
+    const int nw = special ? level + 1 : level, polys = 2, R = n_rot;
+    const size_t N = (size_t)c->N;
+    const u32 n = (u32)c->N;
+    ks_arg_t A;
+    memset(&A, 0, sizeof A);
+    A.level = level; A.nw = nw; A.special = special; A.polys = polys;
+    A.w.n = nw;
+    for (int j = 0; j < level; j++) A.w.idx[j] = j;
+    if (special) A.w.idx[level] = Lk - 1;
+    limb_sel_t sl;
+    sl.n = level;
+    for (int j = 0; j < level; j++) sl.idx[j] = j;
+    rescale_arg_t ra;
+    memset(&ra, 0, sizeof ra);
+    if (special) {
+        const u64 P = c->q[Lk - 1];
+        for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+    }
+    rot_tail_arg_t G;
+    memset(&G, 0, sizeof G);
+    const u64 m2 = 2 * (u64)c->N;
+    for (int r = 0; r < R; r++) {
+        u64 gi = 1;  // g^-1 modulo 2N by Newton iteration (g odd)
+        for (int i = 0; i < 6; i++) gi = (gi * (2 - galois[r] * gi)) & (m2 - 1);
+        G.ginv[r] = gi;
+    }
+    // workspace per ciphertext: digits (level nw rows) + S / T (R 2 nw) + rotated ciphertexts (R 2 level) + the ciphertext's own transform (2 level)
+    const size_t per_ct = ((size_t)level * nw + (size_t)R * 2 * nw + (size_t)R * 2 * level + (size_t)2 * level) * N * 8;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)((8192ull << 20) / per_ct)}));
+    const size_t ntt_rows = (size_t)chunk * std::max<size_t>({(size_t)level * nw, (size_t)R * 2 * nw, (size_t)2 * level});
+    const size_t ntt_tmp = c->logN > 14 ? ntt_rows * N * 8 : 0;
+    void* ws = nullptr;
+    int rc = ensure_ws(c, ntt_tmp + chunk * per_ct, &ws);
+    if (rc) return rc;
+    u64* dig = (u64*)((char*)ws + ntt_tmp);
+    u64* S = dig + (size_t)chunk * level * nw * N;
+    u64* ROT = S + (size_t)chunk * R * 2 * nw * N;
+    u64* X = ROT + (size_t)chunk * R * 2 * level * N;
+    for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
+        const int64_t nb = std::min(chunk, batch - b0);
+        const u64* cin = ct + (size_t)b0 * polys * level * N;
+        if (R) {
+            rc = ks_digits_fwd(c, A, cin, dig, nb);
+            if (rc) return rc;
+            for (int r = 0; r < R; r++) {   // key sums of the unrotated digits against the prepared key of rotation r
+                rc = ks_inner_launch(c, A, Lk, evks[r], dig, S + (size_t)r * nb * 2 * nw * N, nb);
+                if (rc) return rc;
+            }
+            rc = run_ntt(c, true, S, S, (int64_t)R * nb * 2 * nw, A.w);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_ks_rot_tail, row_grid((unsigned)((int64_t)R * nb * 2 * level), N), dim3(256), 0, c->stream, S, cin, ROT, c->limbs_dev, A, ra, G, n, (u32)nb);
+            HIP_TRY(hipGetLastError());
+            rc = run_ntt(c, false, ROT, ROT, (int64_t)R * nb * 2 * level, sl);
+            if (rc) return rc;
+        }
+        rc = run_ntt(c, false, cin, X, nb * 2 * level, sl);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_matmul_acc, row_grid((unsigned)(nb * 2 * level), N), dim3(256), 0, c->stream, X, ROT, diags, out + (size_t)b0 * 2 * level * N,
+                           c->limbs_dev, sl, n, (u32)R, (u32)(nb * 2 * level));
+        HIP_TRY(hipGetLastError());
+    }
+    return TFHE_OK;
 }
 
 // ---- digit-window key switch (relin_window != 0, rlwe_she.jl:330-338) -----------------------------------------------

@@ -112,6 +112,7 @@ def lib():
         "tfhe_mul": [vp, vp, vp, vp, i64, i32, i32p],
         "tfhe_mad": [vp, vp, vp, vp, vp, i64, i32, i32p],
         "tfhe_dot": [vp, vp, C.POINTER(vp), C.POINTER(vp), i32, vp, i64, i32, i32p],
+        "tfhe_lincomb": [vp, u64p, C.POINTER(vp), i32, vp, i64, i32, i32p],
         "tfhe_scalar_mul": [vp, u64p, vp, vp, i64, i32, i32p],
         "tfhe_tensor": [vp, vp, vp, vp, i64, i32, i32p],
         "tfhe_rescale": [vp, vp, vp, i64, i32, i32p],
@@ -122,6 +123,7 @@ def lib():
         "tfhe_keyswitch_window": [vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i64],
         "tfhe_rotate_many": [vp, i32, i32, i32, C.POINTER(vp), i32, i32, u64p, i32, vp, vp, i64],
         "tfhe_galois_key_prepare": [vp, i32, i32, u64, vp, vp],
+        "tfhe_matmul_diag": [vp, i32, i32, i32, C.POINTER(vp), i32, u64p, i32, vp, vp, vp, i64],
         "tfhe_sample_uniform": [vp, i32, u64, C.c_uint32, u64, vp, i64],
         "tfhe_sample_gaussian": [vp, i32, C.c_double, u64, u64, C.c_uint32, u64, vp, i64],
         "tfhe_ckks_encode": [vp, i32, u64, i32, vp, vp, i64],
@@ -154,7 +156,7 @@ EXPORTED_SYMBOLS = [
     "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_wait_for", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
     "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_pack_poly", "tfhe_unpack_poly", "tfhe_broadcast_poly", "tfhe_alloc_stats", "tfhe_alloc_trim", "tfhe_comm_id", "tfhe_comm_create", "tfhe_comm_destroy", "tfhe_gather", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
     "tfhe_mul", "tfhe_mad", "tfhe_dot", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
-    "tfhe_keyswitch", "tfhe_rotate", "tfhe_rotate_many", "tfhe_galois_key_prepare", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
+    "tfhe_keyswitch", "tfhe_rotate", "tfhe_rotate_many", "tfhe_galois_key_prepare", "tfhe_matmul_diag", "tfhe_lincomb", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
     "tfhe_bfv_plan_set_variant", "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
     "tfhe_event_create", "tfhe_event_destroy", "tfhe_event_record", "tfhe_event_elapsed_ms",
 ]
@@ -300,6 +302,21 @@ class Context:
         A = (C.c_void_p * n)(*a_ptrs)
         B = (C.c_void_p * n)(*b_ptrs)
         check(lib().tfhe_dot(self.h, acc, A, B, n, dst, count, limbs, _idx(idx)))
+
+    def lincomb(self, scalars, a_ptrs, dst, count, limbs, idx=None):
+        """dst = sum_k scalars[k] * a_k (tfhe_lincomb); scalars: [n_terms][limbs] residues, a_ptrs: device pointers"""
+        n = len(a_ptrs)
+        flat = [int(x) for row in scalars for x in row]
+        if len(flat) != n * limbs:
+            raise AssertionError("tfhe_lincomb: one scalar per term and limb")
+        S = (C.c_uint64 * len(flat))(*flat)
+        A = (C.c_void_p * n)(*a_ptrs)
+        check(lib().tfhe_lincomb(self.h, S, A, n, dst, count, limbs, _idx(idx)))
+
+    def matmul_diag(self, key_limbs, level, special, evks, n_digits, gs, diags, ct, out, batch):
+        ptrs = (C.c_void_p * max(1, len(evks)))(*[int(p) for p in evks])
+        garr = (C.c_uint64 * max(1, len(gs)))(*[int(g) for g in gs])
+        check(lib().tfhe_matmul_diag(self.h, key_limbs, level, int(bool(special)), ptrs, n_digits, garr, len(evks), diags, ct, out, batch))
 
     def scalar_mul(self, scal, a, dst, count, limbs, idx=None):
         s = (C.c_uint64 * limbs)(*[int(x) for x in scal])

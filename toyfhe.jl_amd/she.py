@@ -409,6 +409,36 @@ class CipherText:
             out.append(RingElement(ring, None, o, batch))
         return CipherText(c0.params, out, Fraction(c0.scale) ** 2)
 
+    @staticmethod
+    def lincomb(cts, weights) -> "CipherText":
+        """sum_k cts[k] * weights[k] for float weights (ct * float, ckksencoding.jl:99-102, and the + of rlwe_she.jl:231-245 per
+        term): the scalar-weighted sums of a convolution over encrypted inputs (infer.jl:127-129) as ONE device pass per
+        component (tfhe_lincomb); bit-identical to `sum(c.mul_plain(w) for c, w in zip(cts, weights))`."""
+        cts, weights = list(cts), [float(w) for w in weights]
+        if not cts or len(cts) != len(weights):
+            raise AssertionError("lincomb: as many ciphertexts as weights, at least one")
+        c0 = cts[0]
+        c0._need_scale()
+        ring, n, batch = c0.ring(), c0[0].count, c0[0].batch
+        for c in cts:
+            if c.ring() != ring or len(c) != len(c0) or c.scale != c0.scale or c[0].count != n:
+                raise UsageError("lincomb: ciphertexts of one ring, length, batch and scale")
+        scal = []
+        for w in weights:                                 # FixedRational(w).x at the ciphertext's scale, ckks.jl:42 (ties to even)
+            fr = Fraction(w) * Fraction(c0.scale)
+            fl = fr.numerator // fr.denominator
+            rem = fr - fl
+            v = fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2) else 0)
+            scal.append([int(v) % q for q in ring.moduli])
+        primal = all(c.cs[0].primal is not None for c in cts)   # stay in the domain the operands are in
+        out = []
+        for s_ in range(len(c0)):
+            ab = [(c.cs[s_].coeffs_primal() if primal else c.cs[s_].coeffs_dual()) for c in cts]
+            o = DeviceBuffer(n * ring.L * ring.N)
+            ring.ctx.lincomb(scal, [x.ptr for x in ab], o.ptr, n, ring.L, ring.idx)
+            out.append(RingElement(ring, o, None, batch) if primal else RingElement(ring, None, o, batch))
+        return CipherText(c0.params, out, Fraction(c0.scale) ** 2)
+
     def add_plain(self, x) -> "CipherText":
         """ct .+ float / ct .+ vector (:111-124): encoded at the ciphertext's scale and added to the first component."""
         self._need_scale()
@@ -708,6 +738,56 @@ def rotate_many(gks, c: CipherText):
     if ring.ctx is not keyring.ctx:
         ring.ctx.wait_for(keyring.ctx)                     # as in keyswitch: the results live on `ring`, written on the key ring's stream
     return res
+
+
+def matmul_diag(gks, diags, c: CipherText) -> CipherText:
+    """diags[0] .* c + sum_k diags[k] .* rotate(gks[k-1], c): the diagonal matrix-vector product of infer.jl:140-149 /
+    test/ckks_matmul.jl:33-41 with every rotation starting from `c` (one Galois key per step), in ONE device call
+    (tfhe_matmul_diag).  `diags`: len(gks) + 1 plaintext ring elements of c's ring encoded at c's scale (one polynomial each:
+    the same diagonal multiplies every ciphertext of the batch), or ONE batched element holding them back to back (what
+    ckks_encode returns for a [len(gks) + 1][N/2] array of slot vectors).  Bit-identical to
+    `CipherText.dot_plain([c] + rotate_many(gks, c), diags)`; the result is in the NTT domain, at the squared scale."""
+    gks = list(gks)
+    if len(c) != 2:
+        raise AssertionError("rotate takes a 2-element ciphertext")
+    c._need_scale()
+    ring, n, batch = c[0].ring, c[0].count, c[0].batch
+    level = ring.L
+    stacked = isinstance(diags, RingElement)              # one batched element holding the len(gks) + 1 diagonals back to back
+    if stacked:
+        if diags.ring != ring or diags.count != len(gks) + 1:
+            raise UsageError("matmul_diag: a stacked plaintext element must hold one diagonal per rotation plus one")
+    else:
+        diags = list(diags)
+        if len(diags) != len(gks) + 1:
+            raise AssertionError("matmul_diag: one diagonal for the ciphertext itself and one per rotation")
+        for d in diags:
+            if not isinstance(d, RingElement) or d.ring != ring or d.count != 1:
+                raise UsageError("matmul_diag: the diagonals are single plaintext elements of the ciphertext's ring")
+    if gks:
+        params = gks[0].key.params
+        if any(g.key.params is not params for g in gks) or params.relin_window != 0:
+            raise UsageError("hoisted rotations need Galois keys of one parameter set with RNS digits")
+        keyring = gks[0].key.key[0].mask.ring
+        special = isinstance(params, ModulusRaised)
+    else:
+        keyring, special = ring, False
+    if keyring.idx != list(range(keyring.L)) or ring.idx != list(range(level)):
+        raise UsageError("ciphertext ring is not a prefix of the key ring")
+    if ring.ctx is not keyring.ctx:
+        if ring.N != keyring.N or ring.moduli != keyring.moduli[:level] or ring.psi != keyring.psi[:level]:
+            raise UsageError("ciphertext and key belong to different rings")
+        keyring.ctx.wait_for(ring.ctx)
+    sz = level * ring.N
+    dg = diags.coeffs_dual() if stacked else _pack([d.coeffs_dual() for d in diags], ring, 1, ctx=keyring.ctx)   # [R+1][level][N]
+    ct = _pack([x.coeffs_primal() for x in c.cs], ring, n, ctx=keyring.ctx)
+    out = DeviceBuffer(n * 2 * sz)
+    keyring.ctx.matmul_diag(keyring.L, level, special, [g.prepared().ptr for g in gks], len(gks[0].key.key) if gks else level,
+                            [g.galois_element for g in gks], dg.ptr, ct.ptr, out.ptr, n)
+    res = _unpack(out, ring, n, 2, batch, primal=False, ctx=keyring.ctx)
+    if ring.ctx is not keyring.ctx:
+        ring.ctx.wait_for(keyring.ctx)
+    return CipherText(c.params, res, Fraction(c.scale) ** 2)
 
 
 class _View:
