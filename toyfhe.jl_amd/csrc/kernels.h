@@ -1243,6 +1243,33 @@ __global__ __launch_bounds__(256) void k_galois(const u64* __restrict__ src, u64
     }
 }
 
+// The same automorphism for rows beyond the LDS (N >= 2^15) in scatter form with an XCD-cooperative walk (see k_ks_rot_tail):
+// the workgroups of one XCD share one polynomial (its `limbs` rows: the same index map, different moduli for the sign) at a
+// time, so the scattered 8-byte stores land in windows that stay in that XCD's L2 until they are complete; reads are coalesced.
+// rows = polys * limbs, row r uses modulus sel.idx[r % limbs].
+__global__ __launch_bounds__(256) void k_galois_xcd(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                     const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u64 g, u32 n, u32 npolys) {
+    __shared__ u64 lq[TFHE_MAX_LIMBS];
+    const u32 limbs = (u32)sel.n;
+    for (u32 j = threadIdx.x; j < limbs; j += blockDim.x) lq[j] = LT[sel.idx[j]].q;
+    __syncthreads();
+    const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const u64 mask2n = 2ull * n - 1;
+    for (u32 p = xcd; p < npolys; p += 8u) {
+        const u64* s0 = src + (size_t)p * limbs * n;
+        u64* d0 = dst + (size_t)p * limbs * n;
+        for (u32 i = slot * blockDim.x + threadIdx.x; i < n; i += nslot * blockDim.x) {
+            const u64 t = ((u64)i * g) & mask2n;
+            const bool neg = t >= n;
+            const u32 m = (u32)t & (n - 1);
+            for (u32 j = 0; j < limbs; j++) {
+                const u64 v = s0[(size_t)j * n + i];
+                d0[(size_t)j * n + m] = neg ? negmod(v, lq[j]) : v;
+            }
+        }
+    }
+}
+
 // The same automorphism for rows that fit the LDS (N <= 2^14) in scatter form through the LDS: the row is read with coalesced
 // 16-byte loads, every word is written to LDS position g*i mod N (odd stride: the 32 lanes of a half-wave hit 32 different
 // bank pairs -- conflict-free), and the permuted row is read back linearly and stored with coalesced 16-byte stores.  The
@@ -1306,10 +1333,18 @@ struct ks_arg_t {
 // (rlwe_she.jl:340-344).  One thread owns coefficient k of limb j for the WHOLE chunk of ciphertexts, so the
 // evaluation-key values are loaded once into registers and reused across the batch (the key is shared by
 // all ciphertexts; re-reading it per ciphertext was the dominant traffic).  grid = nw * ceil(N/256).
+// several keys against the same digits in one launch (the rotations of a diagonal product, tfhe_matmul_diag): blockIdx.y
+// selects the key and the slice of S it writes; n == 0: the single key `evk`
+struct ks_keys_t {
+    int n;
+    size_t s_stride;  // words of S per key
+    const u64* key[TFHE_DOT_MAX];
+};
 template <int DCH>
 __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, const u64* __restrict__ dig,
                                                    u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
-                                                   int Lk, u32 n, u32 batch, u32 bsplit, u32 limb_mask) {
+                                                   int Lk, u32 n, u32 batch, u32 bsplit, u32 limb_mask, ks_keys_t K) {
+    if (K.n) { evk = K.key[blockIdx.y]; S += (size_t)blockIdx.y * K.s_stride; }
     // blockIdx.x = (slice * nw + j) * gx + tile; slice = which part of the batch this workgroup owns
     const u32 gx = (n + 255) / 256, tile = blockIdx.x % gx, j = (blockIdx.x / gx) % (u32)A.nw, slice = blockIdx.x / (gx * (u32)A.nw);
     if (limb_mask && !((limb_mask >> j) & 1u)) return;  // rings of mixed modulus sizes: the narrow kernel takes the other limbs
@@ -1360,7 +1395,8 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
 template <int DCH>
 __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk, const u64* __restrict__ dig,
                                                       u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
-                                                      int Lk, u32 n, u32 batch, u32 bsplit, u32 limb_mask) {
+                                                      int Lk, u32 n, u32 batch, u32 bsplit, u32 limb_mask, ks_keys_t K) {
+    if (K.n) { evk = K.key[blockIdx.y]; S += (size_t)blockIdx.y * K.s_stride; }
     static_assert(DCH + 1 <= 16, "acc52 term budget");
     const u32 gx = (n / 2 + 255) / 256, tile = blockIdx.x % gx, j = (blockIdx.x / gx) % (u32)A.nw, slice = blockIdx.x / (gx * (u32)A.nw);
     if (limb_mask && !((limb_mask >> j) & 1u)) return;
@@ -1983,39 +2019,68 @@ __global__ __launch_bounds__(256) void k_ks_rescale_add(const u64* __restrict__ 
 // inverse-transformed key sums of the unrotated digits; rotation r's result is sigma_g( . ) applied per limb in the coefficient
 // domain (a signed permutation, BEFORE the floor of the ModulusRaised contraction, which does not commute with sign changes;
 // see ks_finish), then out_j = sigma_g(c)_j + (T'_j - [T'_P]) P^-1 (special) or sigma_g(c)_j + T'_j, for s = 0 only the addend.
-// Gather form: output coefficient m takes source coefficient i0 = m g^-1 mod 2N (sign = i0 >= N).  out: [R][batch][2][level][N].
+// Scatter form: the three source rows (T_j, T_P, c_j) are read in order -- coalesced -- and coefficient i goes to position
+// g i mod N with the sign of floor(g i / N); the 8-byte stores of a row land in a 512 KiB window that stays in the L2 until its
+// lines are complete.  (The gather form -- three scattered 8-byte reads per output -- ran at 0.85 TB/s and was 38 % of the
+// encrypted-MNIST evaluation; a gather is bound by the texture addresser, ~8 B/clk/CU.)  out: [R][batch][2][level][N].
 struct rot_tail_arg_t {
-    u64 ginv[TFHE_DOT_MAX];
+    u64 g[TFHE_DOT_MAX];
 };
+// Walk: a permutation of a row uses every cache line of its window 16 times over the WHOLE row, so the window must stay in
+// the L2 until the row is done -- with one workgroup per row and a few thousand rows in flight the windows were evicted half
+// written and every 8-byte store became a read-modify-write in HBM (4.0 ms per launch = 0.8 TB/s, scatter and gather alike).
+// Here the workgroups of one XCD (blockIdx.x & 7 -- workgroups are dealt to the XCDs round-robin) share ONE row group
+// (r, b, s) at a time, each taking a slice of the coefficients, so an XCD's 4 MiB L2 holds one or two groups' windows
+// (level x N x 8 bytes each); T_P[i] is read once per coefficient for all limbs.
+#ifndef TFHE_ROT_TAIL_SLOTS
+#define TFHE_ROT_TAIL_SLOTS 128  // workgroups per XCD (measured on the encrypted-MNIST circuit at N = 2^16: 64 -> 43.9 k, 128 -> 46.0 k, 256 -> 41.7 k images/s)
+#endif
 __global__ __launch_bounds__(256) void k_ks_rot_tail(const u64* __restrict__ T, const u64* __restrict__ ct, u64* __restrict__ out,
                                                       const ntt_limb_t* __restrict__ LT, ks_arg_t A, rescale_arg_t ra, rot_tail_arg_t G,
-                                                      u32 n, u32 batch) {
+                                                      u32 n, u32 batch, u32 ngroups) {
+    __shared__ u64 lq[TFHE_MAX_LIMBS], lmu[TFHE_MAX_LIMBS], lw[TFHE_MAX_LIMBS], lwp[TFHE_MAX_LIMBS];
+    __shared__ u32 lsh[TFHE_MAX_LIMBS];
     const u32 level = (u32)A.level, nw = (u32)A.nw;
-    const u32 row = blockIdx.x, j = row % level, s = (row / level) & 1u, b = (row / (2u * level)) % batch, r = row / (2u * level * batch);
-    const ntt_limb_t L = LT[A.w.idx[j]];
+    for (u32 j = threadIdx.x; j < level; j += blockDim.x) {
+        const ntt_limb_t& L = LT[A.w.idx[j]];
+        lq[j] = L.q; lmu[j] = L.br.mu; lsh[j] = L.br.sh; lw[j] = ra.qlinv[j].w; lwp[j] = ra.qlinv[j].wp;
+    }
+    __syncthreads();
     const u64 P = A.special ? LT[A.w.idx[level]].q : 0;
-    const u64* tj = T + ((((size_t)r * batch + b) * 2 + s) * nw + j) * n;
-    const u64* tl = T + ((((size_t)r * batch + b) * 2 + s) * nw + level) * n;
-    const u64* c = s == 0 ? ct + (((size_t)b * 2 + 0) * level + j) * n : nullptr;   // 2-element input: only c_1 has an addend (rlwe_she.jl:324)
-    u64* o = out + (size_t)row * n;
-    const u64 ginv = G.ginv[r], mask2n = 2ull * n - 1;
-    for (u32 m = blockIdx.y * blockDim.x + threadIdx.x; m < n; m += gridDim.y * blockDim.x) {
-        const u64 i0 = ((u64)m * ginv) & mask2n;
-        const u32 i = (u32)(i0 & (n - 1));
-        const bool neg = i0 >= n;
-        u64 v = tj[i];
-        if (neg) v = negmod(v, L.q);
-        if (A.special) {
-            u64 last = tl[i];
-            if (neg) last = negmod(last, P);
-            v = shoup_full(submod(v, barrett_reduce128(last, 0, L.br), L.q), ra.qlinv[j], L.q);
+    const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const u64 mask2n = 2ull * n - 1;
+    for (u32 grp = xcd; grp < ngroups; grp += 8u) {   // grp = (r * batch + b) * 2 + s
+        const u32 s = grp & 1u, b = (grp >> 1) % batch, r = (grp >> 1) / batch;
+        const u64 g = G.g[r];
+        const u64* tg = T + (size_t)grp * nw * n;
+        const u64* tl = tg + (size_t)level * n;
+        const u64* cg = s == 0 ? ct + ((size_t)b * 2 * level) * n : nullptr;   // 2-element input: only c_1 has an addend (rlwe_she.jl:324)
+        u64* og = out + (size_t)grp * level * n;
+        for (u32 i = slot * blockDim.x + threadIdx.x; i < n; i += nslot * blockDim.x) {
+            const u64 t = ((u64)i * g) & mask2n;
+            const bool neg = t >= n;
+            const u32 m = (u32)t & (n - 1);
+            u64 last = 0;
+            if (A.special) {
+                last = tl[i];
+                if (neg) last = negmod(last, P);
+            }
+            for (u32 j = 0; j < level; j++) {
+                const u64 q = lq[j];
+                u64 v = tg[(size_t)j * n + i];
+                if (neg) v = negmod(v, q);
+                if (A.special) {
+                    const barrett_t br{q, lmu[j], lsh[j]};
+                    v = shoup_full(submod(v, barrett_reduce128(last, 0, br), q), tw_t{lw[j], lwp[j]}, q);
+                }
+                if (cg) {
+                    u64 a = cg[(size_t)j * n + i];
+                    if (neg) a = negmod(a, q);
+                    v = addmod(v, a, q);
+                }
+                og[(size_t)j * n + m] = v;
+            }
         }
-        if (c) {
-            u64 a = c[i];
-            if (neg) a = negmod(a, L.q);
-            v = addmod(v, a, L.q);
-        }
-        o[m] = v;
     }
 }
 

@@ -877,6 +877,15 @@ static int do_galois(tfhe_ctx* c, const u64* src, u64* dst, u64 g, int64_t rows,
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
+#ifndef TFHE_GALOIS_XCD
+#define TFHE_GALOIS_XCD 1
+#endif
+    if (TFHE_GALOIS_XCD && c->variant == 0 && c->logN >= 15 && rows % sel.n == 0 && rows / sel.n >= 16) {
+        // whole polynomials, enough of them: the XCD-cooperative scatter (k_galois_xcd)
+        hipLaunchKernelGGL(k_galois_xcd, dim3(8 * TFHE_ROT_TAIL_SLOTS), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, g, (u32)c->N, (u32)(rows / sel.n));
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
     hipLaunchKernelGGL(k_galois, row_grid((unsigned)rows, (size_t)c->N), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, ginv, (u32)c->N);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
@@ -969,8 +978,19 @@ static int ks_digits_fwd(tfhe_ctx* c, const ks_arg_t& A, const u64* ct, u64* dig
 
 static int do_galois(tfhe_ctx* c, const u64* src, u64* dst, u64 g, int64_t rows, const limb_sel_t& sel);
 // S_s = sum_i evk_{i,s} (.) digit_i over the working limbs (NTT domain), S: [batch][2][nw][N]
-static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, const u64* dig, u64* S, int64_t batch) {
+// keys != nullptr: `nkeys` keys against the same digits in one launch, key r writing S + r * batch*2*nw*N (tfhe_matmul_diag)
+static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, const u64* dig, u64* S, int64_t batch,
+                           const uint64_t* const* keys = nullptr, int nkeys = 0) {
     const int nw = A.nw;
+    ks_keys_t K;
+    memset(&K, 0, sizeof K);
+    if (keys) {
+        K.n = nkeys;
+        K.s_stride = (size_t)batch * 2 * nw * (size_t)c->N;
+        for (int r = 0; r < nkeys; r++) K.key[r] = keys[r];
+        evk = keys[0];
+    }
+    const unsigned gy = keys ? (unsigned)nkeys : 1u;
     const u32 n = (u32)c->N;
     const unsigned gx = (n + 255) / 256;
     // enough workgroups to fill the chip: split the batch into slices (the key is re-read once per slice)
@@ -983,12 +1003,12 @@ static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* ev
     if (nmask) {
         const unsigned gx2 = (n / 2 + 255) / 256;
         const unsigned bs2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx2 - 1) / (nw * gx2)));
-        hipLaunchKernelGGL(k_ks_inner_n2<8>, dim3((unsigned)nw * gx2 * bs2), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2,
-                           nmask == amask ? 0u : nmask);
+        hipLaunchKernelGGL(k_ks_inner_n2<8>, dim3((unsigned)nw * gx2 * bs2, gy), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2,
+                           nmask == amask ? 0u : nmask, K);
     }
     if (nmask != amask) {
-        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit,
-                           nmask ? (amask & ~nmask) : 0u);
+        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit, gy), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit,
+                           nmask ? (amask & ~nmask) : 0u, K);
     }
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
@@ -1357,12 +1377,7 @@ int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
     }
     rot_tail_arg_t G;
     memset(&G, 0, sizeof G);
-    const u64 m2 = 2 * (u64)c->N;
-    for (int r = 0; r < R; r++) {
-        u64 gi = 1;  // g^-1 modulo 2N by Newton iteration (g odd)
-        for (int i = 0; i < 6; i++) gi = (gi * (2 - galois[r] * gi)) & (m2 - 1);
-        G.ginv[r] = gi;
-    }
+    for (int r = 0; r < R; r++) G.g[r] = galois[r];
     // workspace per ciphertext: digits (level nw rows) + S / T (R 2 nw) + rotated ciphertexts (R 2 level) + the ciphertext's own transform (2 level)
     const size_t per_ct = ((size_t)level * nw + (size_t)R * 2 * nw + (size_t)R * 2 * level + (size_t)2 * level) * N * 8;
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)((8192ull << 20) / per_ct)}));
@@ -1381,13 +1396,12 @@ int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
         if (R) {
             rc = ks_digits_fwd(c, A, cin, dig, nb);
             if (rc) return rc;
-            for (int r = 0; r < R; r++) {   // key sums of the unrotated digits against the prepared key of rotation r
-                rc = ks_inner_launch(c, A, Lk, evks[r], dig, S + (size_t)r * nb * 2 * nw * N, nb);
-                if (rc) return rc;
-            }
+            rc = ks_inner_launch(c, A, Lk, nullptr, dig, S, nb, evks, R);   // key sums of the unrotated digits against every prepared key
+            if (rc) return rc;
             rc = run_ntt(c, true, S, S, (int64_t)R * nb * 2 * nw, A.w);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_ks_rot_tail, row_grid((unsigned)((int64_t)R * nb * 2 * level), N), dim3(256), 0, c->stream, S, cin, ROT, c->limbs_dev, A, ra, G, n, (u32)nb);
+            hipLaunchKernelGGL(k_ks_rot_tail, dim3(8 * TFHE_ROT_TAIL_SLOTS), dim3(256), 0, c->stream, S, cin, ROT, c->limbs_dev, A, ra, G, n, (u32)nb,
+                               (u32)((int64_t)R * nb * 2));
             HIP_TRY(hipGetLastError());
             rc = run_ntt(c, false, ROT, ROT, (int64_t)R * nb * 2 * level, sl);
             if (rc) return rc;
@@ -1492,7 +1506,9 @@ int tfhe_keyswitch_window(tfhe_ctx* c, int key_limbs, int level, int special, in
         rc = run_ntt(c, false, dig, dig, nb * need * nw, A.w);
         if (rc) return rc;
         const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nb, (4096 + nw * gx - 1) / (nw * gx)));
-        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)nb, bsplit, 0u);
+        ks_keys_t K1;
+        memset(&K1, 0, sizeof K1);
+        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)nb, bsplit, 0u, K1);
         HIP_TRY(hipGetLastError());
         if (special) {
             // ModulusRaised: c1 = P c + S over [q_0 .. q_{level-1}, P], contracted by modswitch (modulusraising.jl:35-42):

@@ -660,12 +660,13 @@ def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
         level = ring.L
         if keyring.idx != list(range(keyring.L)) or ring.idx != list(range(level)) or level > keyring.L - (1 if special else 0):
             raise UsageError("window key switch: the ciphertext ring must be a prefix of the key ring")
+        cs = c.cs if _galois is None else [x.apply_galois_element(_galois) for x in c.cs]
+        prim = [x.coeffs_primal() for x in cs]            # may enqueue inverse transforms on the ciphertext ring's stream: BEFORE the hand-over
         if ring.ctx is not keyring.ctx:
             if ring.N != keyring.N or ring.moduli != keyring.moduli[:level] or ring.psi != keyring.psi[:level]:
                 raise UsageError("ciphertext and key belong to different rings")
             keyring.ctx.wait_for(ring.ctx)
-        cs = c.cs if _galois is None else [x.apply_galois_element(_galois) for x in c.cs]
-        ct = _pack([x.coeffs_primal() for x in cs], ring, n, ctx=keyring.ctx)
+        ct = _pack(prim, ring, n, ctx=keyring.ctx)
         out = DeviceBuffer(n * 2 * level * ring.N)
         keyring.ctx.keyswitch_window(level, params.relin_window, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n,
                                      key_limbs=keyring.L, special=special)
@@ -681,9 +682,10 @@ def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
     if ring.ctx is not keyring.ctx and (ring.N != keyring.N or ring.moduli != keyring.moduli[:level] or ring.psi != keyring.psi[:level]):
         raise UsageError("ciphertext and key belong to different rings")
     sz = level * ring.N
+    prim = [x.coeffs_primal() for x in c.cs]               # may enqueue inverse transforms on the ciphertext ring's stream ...
     if ring.ctx is not keyring.ctx:
-        keyring.ctx.wait_for(ring.ctx)                     # the components were produced on the ciphertext ring's stream
-    ct = _pack([x.coeffs_primal() for x in c.cs], ring, n, ctx=keyring.ctx)
+        keyring.ctx.wait_for(ring.ctx)                     # ... so the hand-over to the key ring's stream comes after them
+    ct = _pack(prim, ring, n, ctx=keyring.ctx)
     out = DeviceBuffer(n * 2 * sz)
     if _galois is None:
         keyring.ctx.keyswitch(keyring.L, level, special, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n)
@@ -722,12 +724,13 @@ def rotate_many(gks, c: CipherText):
     level, special = ring.L, isinstance(params, ModulusRaised)
     if keyring.idx != list(range(keyring.L)) or ring.idx != list(range(level)):
         raise UsageError("ciphertext ring is not a prefix of the key ring")
+    prim = [x.coeffs_primal() for x in c.cs]               # before the hand-over (see keyswitch)
     if ring.ctx is not keyring.ctx:
         if ring.N != keyring.N or ring.moduli != keyring.moduli[:level] or ring.psi != keyring.psi[:level]:
             raise UsageError("ciphertext and key belong to different rings")
         keyring.ctx.wait_for(ring.ctx)
     sz = level * ring.N
-    ct = _pack([x.coeffs_primal() for x in c.cs], ring, n, ctx=keyring.ctx)
+    ct = _pack(prim, ring, n, ctx=keyring.ctx)
     out = DeviceBuffer(len(gks) * n * 2 * sz)
     keyring.ctx.rotate_many(keyring.L, level, special, [g.prepared().ptr for g in gks], len(gks[0].key.key),
                             [g.galois_element for g in gks], ct.ptr, out.ptr, n, prepared=True)
@@ -774,13 +777,15 @@ def matmul_diag(gks, diags, c: CipherText) -> CipherText:
         keyring, special = ring, False
     if keyring.idx != list(range(keyring.L)) or ring.idx != list(range(level)):
         raise UsageError("ciphertext ring is not a prefix of the key ring")
+    prim = [x.coeffs_primal() for x in c.cs]               # both before the hand-over (see keyswitch)
+    duals = [diags.coeffs_dual()] if stacked else [d.coeffs_dual() for d in diags]
     if ring.ctx is not keyring.ctx:
         if ring.N != keyring.N or ring.moduli != keyring.moduli[:level] or ring.psi != keyring.psi[:level]:
             raise UsageError("ciphertext and key belong to different rings")
         keyring.ctx.wait_for(ring.ctx)
     sz = level * ring.N
-    dg = diags.coeffs_dual() if stacked else _pack([d.coeffs_dual() for d in diags], ring, 1, ctx=keyring.ctx)   # [R+1][level][N]
-    ct = _pack([x.coeffs_primal() for x in c.cs], ring, n, ctx=keyring.ctx)
+    dg = duals[0] if stacked else _pack(duals, ring, 1, ctx=keyring.ctx)   # [R+1][level][N]
+    ct = _pack(prim, ring, n, ctx=keyring.ctx)
     out = DeviceBuffer(n * 2 * sz)
     keyring.ctx.matmul_diag(keyring.L, level, special, [g.prepared().ptr for g in gks], len(gks[0].key.key) if gks else level,
                             [g.galois_element for g in gks], dg.ptr, ct.ptr, out.ptr, n)
