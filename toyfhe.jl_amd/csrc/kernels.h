@@ -930,6 +930,111 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_subpair(const u64* __rest
     }
 }
 
+// N = 2^(LOGB+2) inverse transform in ONE kernel, one row per workgroup pass: the four 2^LOGB sub-blocks are inverse-transformed
+// two at a time (sub-blocks ph and ph + 2 share their natural-order 16-byte pieces, as k_ntt_inv_subpair), their results --
+// reduced doubles -- parked in a per-workgroup scratch row (4 x 2^LOGB words; a thread reads back exactly the words it
+// wrote, so there is no exchange between threads and no synchronisation: the scratch only extends the register file, and at
+// 512 KiB per workgroup it lives in the L2 / Infinity Cache), then every thread runs the two top stages on its columns
+// (4 sub-block values per column: two Gentleman-Sande stages, N^-1 folded into the last) and stores the row.  HBM traffic is
+// one read and one write of the row (2 N 8 bytes) instead of the 4 N 8 of k_ntt_inv_subpair + k_ntt_inv_top<2>; a row is
+// read completely before any of it is written, so in place is fine.
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_quad(const u64* __restrict__ src, u64* __restrict__ dst, u64* __restrict__ scratch,
+                                                             const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nrows, u32 limb_mask) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int X = 2;
+    constexpr int K1 = pass_k_inv(LOGB, LOGT, LOGB), S1 = LOGB - K1;
+    typedef pgeom<LOGB, LOGT, S1, K1> G1;
+    constexpr int E = G1::E;
+    constexpr int K2 = pass_k_inv(LOGB, LOGT, S1), KL = S1 - K2;  // middle and last pass widths
+    static_assert(KL >= 1 && pass_k_inv(LOGB, LOGT, KL) == KL, "three-pass schedule expected");
+    typedef pgeom<LOGB, LOGT, 0, KL> GL;
+    static_assert(GL::SETS * GL::R == E, "last pass geometry");
+    const size_t ntot = (size_t)1 << (LOGB + X);
+    u64* const scr = scratch + ((size_t)blockIdx.x << (LOGB + X));
+    bool first = true;
+    for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
+        if (limb_mask && !((limb_mask >> (row % (u32)sel.n)) & 1u)) continue;
+        const typename A::ctx C = A::make(LT[sel.idx[row % (u32)sel.n]]);
+#pragma unroll 1
+        for (u32 ph = 0; ph < 2; ph++) {
+            const u64* s = src + row * ntot + brev_bits(ph, X);
+            u64 raw[2][E];
+            {
+                const u32 tid = fresh_tid();
+#pragma unroll
+                for (int u = 0; u < G1::SETS; u++) {
+                    u32 c0, hi, base;
+                    G1::template coords<true>(tid, u, c0, hi, base);
+#pragma unroll
+                    for (int r = 0; r < G1::R; r++) {
+                        const u32 nat = (brev_bits((u32)r, K1) << (LOGB - K1)) + c0;
+                        const u64x2_t w = *(const u64x2_t*)(s + ((u64)nat << X));
+                        raw[0][u * G1::R + r] = w.x;
+                        raw[1][u * G1::R + r] = w.y;
+                    }
+                }
+                TFHE_SCHED_FENCE();
+            }
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const u32 sb = ph + ((u32)half << (X - 1)), pre = (1u << X) + sb;
+                u64* g = scr + ((size_t)sb << LOGB);
+                const u32 tid = fresh_tid();
+                if (!first) __syncthreads();
+                first = false;
+                {
+                    typename A::elem v[E];
+                    inv_compute<A, LOGB, LOGT, S1, K1, true, false, 0>(v, raw[half], nullptr, C, tid, pre);
+                    inv_store<A, LOGB, LOGT, S1, K1, true, false>(v, lds, nullptr, C, tid);
+                }
+                __syncthreads();
+                ntt_inv_pass<A, LOGB, LOGT, KL, K2, false, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+                __syncthreads();
+                ntt_inv_pass<ArithFpD, LOGB, LOGT, 0, KL, false, true, false>(lds, nullptr, g, C, tid, pre, 0, 0u);   // parked as reduced doubles
+            }
+        }
+        // top stages on this thread's own columns (it wrote exactly these words: same thread -> element map in every sub-block).
+        // The vector L1 is write-through but may still hold the PREVIOUS row's scratch words (same addresses): one acquire
+        // fence invalidates it, then the reads are plain coalesced loads.
+        TFHE_WAIT_VM0();                                   // this wave's parking stores have been written through to the L2
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // L1 invalidate only (a release fence would write the L2 back: 1.1 TB/s)
+        {
+            const u32 tid = fresh_tid();
+            const typename A::tw w2 = A::ld_inv(C, 2u), w3 = A::ld_inv(C, 3u);
+            u64* o = dst + row * ntot;
+            constexpr int CH = 8;  // columns per batch of loads
+#pragma unroll
+            for (int u = 0; u < GL::SETS; u++) {
+                u32 c0, hi, base;
+                GL::template coords<false>(tid, u, c0, hi, base);
+#pragma unroll
+                for (int r0 = 0; r0 < GL::R; r0 += CH) {
+                    u64 zw[CH][4];
+#pragma unroll
+                    for (int r = 0; r < CH; r++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            zw[r][q] = scr[((size_t)q << LOGB) + base + ((u32)(r0 + r) << GL::LO)];
+#pragma unroll
+                    for (int r = 0; r < CH; r++) {
+                        double z0 = A::from_lds(zw[r][0]), z1 = A::from_lds(zw[r][1]), z2 = A::from_lds(zw[r][2]), z3 = A::from_lds(zw[r][3]);
+                        A::bf_inv(z0, z1, w2, C);          // stage 1: pairs (0,1) and (2,3), twiddles Winv[2], Winv[3]
+                        A::bf_inv(z2, z3, w3, C);
+                        A::bf_inv_scaled(z0, z2, C);       // stage 0 with N^-1: pairs (0,2) and (1,3)
+                        A::bf_inv_scaled(z1, z3, C);
+                        const u32 j = base + ((u32)(r0 + r) << GL::LO);
+                        o[j] = A::out_inv_scaled(z0, C);
+                        o[j + (1u << LOGB)] = A::out_inv_scaled(z1, C);
+                        o[j + (2u << LOGB)] = A::out_inv_scaled(z2, C);
+                        o[j + (3u << LOGB)] = A::out_inv_scaled(z3, C);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // top stages of N > 2^LOGB transforms: one column per thread, rows = count*limbs
 template <int X>
 __global__ __launch_bounds__(256) void k_ntt_fwd_top(const u64* __restrict__ src, u64* __restrict__ dst,

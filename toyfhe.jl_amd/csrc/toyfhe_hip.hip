@@ -325,6 +325,34 @@ int run_ntt_large(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t r
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
+    // MEASURED (r03, same box, 512 polys x 7 limbs of 50 bits): 1.75 TB/s against 1.98 for the two-kernel path below (1.64 with
+    // device-scope atomic loads of the parked words instead of an L1-invalidating acquire fence; 1.14 with a release fence, which
+    // writes the L2 back) -- one 512-thread workgroup per CU runs its load, four sub-block transforms, parking, read-back, top
+    // stages and stores strictly one after the other, where the two-kernel path has two workgroups per row in flight and
+    // streaming kernels around them.  Off: the template is not instantiated unless -DTFHE_INV_QUAD=1.
+#ifndef TFHE_INV_QUAD
+#define TFHE_INV_QUAD 0
+#endif
+#if TFHE_INV_QUAD
+    if (inverse && pairable && x == 2 && !iop) {
+        // N = 2^16 inverse in one kernel (k_ntt_inv_quad): one row per workgroup pass, sub-block results parked in a
+        // per-workgroup scratch row, top stages on the thread's own columns
+        constexpr int LOGT = logt_for(14);
+        const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
+        auto qk = k_ntt_inv_quad<ArithFp, 14, LOGT>;
+        static bool iqattr_set = false;
+        if (!iqattr_set) { int rc2 = set_lds(qk, lds); if (rc2) return rc2; iqattr_set = true; }
+        const unsigned grid = (unsigned)std::min<int64_t>(rows, (int64_t)c->num_cus);
+        void* scr = nullptr;
+        int rc2 = ensure_ws(c, (size_t)grid * c->N * 8, &scr);
+        if (rc2) return rc2;
+        prof_begin(c, rows);
+        hipLaunchKernelGGL(qk, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, (u64*)scr, c->limbs_dev, sel, (u32)rows, io.limb_mask);
+        prof_end(c);
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
+#endif
     void* tmp = nullptr;
     int rc = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
     if (rc) return rc;
