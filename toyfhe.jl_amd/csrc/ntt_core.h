@@ -585,48 +585,70 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
                        const u64* addend = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
     constexpr bool TO_GLOBAL = (S0 == 0);
-    u64 o[TO_GLOBAL ? G::E : 1];
-    if (TO_GLOBAL) {
-        // The addend words are requested as ONE block before the results are canonicalised (that arithmetic covers part of
-        // their latency).  Left inside the store loop behind `if (addend)`, each of the 2^(LOGB-LOGT) loads was issued and
-        // awaited on its own (s_waitcnt vmcnt(0), which also drains the previous store): 32 serial round trips per inverse
-        // transform of the fused key switch -- about a fifth of that kernel's time.
-        u64 add[G::E];
+    if constexpr (TO_GLOBAL) {
+        // element e = u * R + r of this thread lives at word base(u) + (r << LO)
+        u32 pos[G::SETS];
+#pragma unroll
+        for (int u = 0; u < G::SETS; u++) {
+            u32 c0, hi;
+            G::template coords<FROM_GLOBAL>(tid, u, c0, hi, pos[u]);
+        }
         if (addend) {
+            // The addend words are requested in blocks, one block ahead of the results they are added to: the canonicalisation of
+            // block q runs under the loads of block q + 1.  History: inside the store loop behind `if (addend)` each of the
+            // 2^(LOGB-LOGT) loads was issued and awaited on its own (s_waitcnt vmcnt(0), which also drains the previous store) --
+            // 32 serial round trips per inverse transform of the fused key switch, a fifth of that kernel's time; requested all
+            // at once they left that kernel three registers short and three of them were spilled right behind their loads,
+            // each with its own wait.  Four blocks keep two of them (E/2 words) in flight next to the results.
+            constexpr int NB = G::E >= 8 ? 4 : 1, BS = G::E / NB;
+            u64 add[2][BS];
+            auto request = [&](int q) {
 #pragma unroll
-            for (int u = 0; u < G::SETS; u++) {
-                if (USEL >= 0 && u != USEL) continue;
-                u32 c0, hi, base;
-                G::template coords<FROM_GLOBAL>(tid, u, c0, hi, base);
+                for (int k = 0; k < BS; k++) {
+                    const int e = q * BS + k, u = e / G::R, r = e % G::R;
+                    if (USEL >= 0 && u != USEL) continue;
+                    add[q & 1][k] = addend[pos[u] + ((u32)r << G::LO)];
+                }
+                TFHE_SCHED_FENCE();
+            };
+            request(0);
 #pragma unroll
-                for (int r = 0; r < G::R; r++) add[u * G::R + r] = addend[base + ((u32)r << G::LO)];
+            for (int q = 0; q < NB; q++) {
+                if (q + 1 < NB) request(q + 1);
+                u64 o[BS];
+#pragma unroll
+                for (int k = 0; k < BS; k++) o[k] = SCALE ? A::out_inv_scaled(v[q * BS + k], C) : A::out_inv_lazy(v[q * BS + k], C);
+                TFHE_SCHED_FENCE();
+#pragma unroll
+                for (int k = 0; k < BS; k++) {
+                    const int e = q * BS + k, u = e / G::R, r = e % G::R;
+                    if (USEL >= 0 && u != USEL) continue;
+                    gdst[pos[u] + ((u32)r << G::LO)] = addmod(o[k], add[q & 1][k], C.q);
+                }
+                TFHE_SCHED_FENCE();
             }
+        } else {
+            // finish every result before the store phase starts (otherwise the scheduler interleaves the two
+            // and the register allocator spills)
+            u64 o[G::E];
+#pragma unroll
+            for (int i = 0; i < G::E; i++) o[i] = SCALE ? A::out_inv_scaled(v[i], C) : A::out_inv_lazy(v[i], C);
             TFHE_SCHED_FENCE();
-        }
-        // finish every result before the store phase starts (otherwise the scheduler interleaves the two
-        // and the register allocator spills)
 #pragma unroll
-        for (int i = 0; i < G::E; i++) o[i] = SCALE ? A::out_inv_scaled(v[i], C) : A::out_inv_lazy(v[i], C);
-        TFHE_SCHED_FENCE();
-        if (addend) {
-#pragma unroll
-            for (int i = 0; i < G::E; i++) {
-                if (USEL >= 0 && i / G::R != USEL) continue;
-                o[i] = addmod(o[i], add[i], C.q);
+            for (int e = 0; e < G::E; e++) {
+                const int u = e / G::R, r = e % G::R;
+                if (USEL >= 0 && u != USEL) continue;
+                gdst[pos[u] + ((u32)r << G::LO)] = o[e];
             }
         }
-    }
+    } else {
 #pragma unroll
-    for (int u = 0; u < G::SETS; u++) {
-        if (USEL >= 0 && u != USEL) continue;
-        u32 c0, hi, base;
-        G::template coords<FROM_GLOBAL>(tid, u, c0, hi, base);
+        for (int u = 0; u < G::SETS; u++) {
+            if (USEL >= 0 && u != USEL) continue;
+            u32 c0, hi, base;
+            G::template coords<FROM_GLOBAL>(tid, u, c0, hi, base);
 #pragma unroll
-        for (int r = 0; r < G::R; r++) {
-            const u32 j = base + ((u32)r << G::LO);
-            if (TO_GLOBAL) {
-                gdst[j] = o[u * G::R + r];
-            } else {
+            for (int r = 0; r < G::R; r++) {
                 typename A::elem e = v[u * G::R + r];
                 A::range_inv(e, C);
                 lds[lds_phi<LOGB, LOGT>(base) + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)] = A::to_lds(e);
