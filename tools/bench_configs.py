@@ -6,7 +6,7 @@ operation on synthetic residues, 1 GPU.  Every case first checks one ciphertext 
   cfg#4        N=2^14,  6 limbs @50 bit + special prime: key switch only                             batch 512 (4096 / 8 GPUs)
   cfg#5  CKKS  N=2^16, the infer.jl ring 60 + 5 x 40 + 60 bit: key switch / rotate / rescale / NTT   batch 64
   cfg#5' same shape on a uniform 50-bit chain (fp64 policy throughout), for comparison
-usage: bench_configs.py [scale]   (scale divides the batches; default 1)"""
+usage: bench_configs.py [scale] [cases]   (scale divides the batches, default 1; cases = positions to run, e.g. 1,3 -- default all)"""
 import os
 import sys
 import time
@@ -116,12 +116,17 @@ def ntt_case(name, N, qs, polys):
                     "inv_frac_of_hbm_peak": gb / t_i / HBM_PEAK_GBS})
 
 
-def run(scale=1, out=None):
+def run(scale=1, out=None, only=None):
     """All cases; returns the list of records (each case asserts one ciphertext against the oracle before it is timed).  A case that
     fails is recorded as {"config": ..., "error": ...} and does not stop the others."""
     del RECORDS[:]
 
+    seen = [0]
+
     def guarded(f, name, *a):
+        seen[0] += 1
+        if only and str(seen[0]) not in str(only).split(","):   # cases by position, 1-based ("1,3")
+            return
         try:
             f(name, *a)
         except Exception as e:  # noqa: BLE001
@@ -146,6 +151,6 @@ def run(scale=1, out=None):
 
 if __name__ == "__main__":
     import json
-    recs = run(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    recs = run(int(sys.argv[1]) if len(sys.argv) > 1 else 1, only=sys.argv[2] if len(sys.argv) > 2 else None)
     for r in recs:
         print(json.dumps(r))

@@ -137,16 +137,33 @@ __device__ __forceinline__ u32 xcd_limb_walk(u32 it, u32 wg, u32 grid, u32 nb, u
     const u32 B = nitems / nb, j = idx / B, b = idx - j * B;
     return b * nb + j;
 }
+// Masked launches (ntt_io_t::limb_mask: rings of mixed modulus sizes, one launch per arithmetic policy): the items of the
+// masked-in limbs numbered DENSELY.  Walking all items and skipping the others resonates with the walk's period -- with 4 or 6
+// limbs per group some workgroups met none of their policy's items and others two to four times their share (the u64 transforms
+// of the encrypted-MNIST products ran 4 x longer than their work).  mask bits lie below `limbs`; mask == 0: identity.
+// An odd number of limbs is coprime to the walks' power-of-two periods and meets every limb evenly as it is: those launches keep
+// the skipping walk (dense_mask returns 0; the reference's 7-limb ring measured 1 % slower with the dense numbering).
+__device__ __forceinline__ u32 dense_mask(u32 limbs, u32 mask) { return (limbs & 1u) ? 0u : mask; }
+__device__ __forceinline__ u32 dense_count(u32 nitems, int x, u32 limbs, u32 mask) {
+    return mask ? ((((nitems >> x) / limbs) * (u32)__popc(mask)) << x) : nitems;
+}
+__device__ __forceinline__ u32 dense_item(u32 d, int x, u32 limbs, u32 mask) {
+    if (!mask || d == ~0u) return d;
+    const u32 nact = (u32)__popc(mask), sb = d & ((1u << x) - 1u), pld = d >> x, g = pld / nact, a = pld % nact;
+    u32 m = mask;
+    for (u32 i = 0; i < a; i++) m &= m - 1u;   // drop the a lowest set bits
+    return ((g * limbs + (u32)__ffs((int)m) - 1u) << x) | sb;
+}
 template <class A, int LOGB, int LOGT, int IOMODE>
 __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_block(const u64* __restrict__ src, u64* __restrict__ dst,
                                                               const ntt_limb_t* __restrict__ LT, limb_sel_t sel, int x,
                                                               u32 nitems, ntt_io_t io) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const size_t ntot = (size_t)1 << (LOGB + x);
-    const u32 niter = (nitems + gridDim.x - 1) / gridDim.x;
+    const u32 dmask = dense_mask((u32)sel.n, io.limb_mask), dn = dense_count(nitems, x, (u32)sel.n, dmask), niter = (dn + gridDim.x - 1) / gridDim.x;
     bool first = true;
     for (u32 it = 0; it < niter; it++) {
-        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x, nitems);
+        const u32 item = dense_item(xcd_walk_item(it, blockIdx.x, gridDim.x, x, dn), x, (u32)sel.n, dmask);
         if (item == ~0u) continue;
         const u32 sb = item & ((1u << x) - 1), pl = item >> x;
         u32 srow = pl, drow = pl, j = pl % (u32)sel.n;
@@ -303,10 +320,10 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_block(const u64* __restri
                                                               u32 nitems, ntt_io_t io) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const size_t ntot = (size_t)1 << (LOGB + x);
-    const u32 niter = (nitems + gridDim.x - 1) / gridDim.x;
+    const u32 dmask = dense_mask((u32)sel.n, io.limb_mask), dn = dense_count(nitems, x, (u32)sel.n, dmask), niter = (dn + gridDim.x - 1) / gridDim.x;
     bool first = true;
     for (u32 it = 0; it < niter; it++) {
-        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x, nitems);
+        const u32 item = dense_item(xcd_walk_item(it, blockIdx.x, gridDim.x, x, dn), x, (u32)sel.n, dmask);
         if (item == ~0u) continue;
         const u32 sb = item & ((1u << x) - 1), pl = item >> x;
         u32 srow = pl, drow = pl, j = pl % (u32)sel.n;
@@ -787,10 +804,10 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
     typedef pgeom<LOGB, LOGT, K1 + K2, K3> G3;
     constexpr int E = G3::E;
     const size_t ntot = (size_t)1 << (LOGB + x);
-    const u32 niter = (nitems + gridDim.x - 1) / gridDim.x;
+    const u32 dmask = dense_mask((u32)sel.n, io.limb_mask), dn = dense_count(nitems, 1, (u32)sel.n, dmask), niter = (dn + gridDim.x - 1) / gridDim.x;
     bool first = true;
     for (u32 it = 0; it < niter; it++) {
-        const u32 item = xcd_walk_item(it, blockIdx.x, gridDim.x, x - 1, nitems);
+        const u32 item = dense_item(xcd_walk_item(it, blockIdx.x, gridDim.x, x - 1, dn), 1, (u32)sel.n, dmask);
         if (item == ~0u) continue;
         const u32 ph = item & 1u, pl = item >> 1;
         u32 srow = pl, j = pl % (u32)sel.n;
@@ -802,6 +819,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
             const ntt_limb_t& Li = LT[sel.idx[i]];
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
+            if (io.lift_unsigned) lf.qi = lf.half = ~0ull;  // no centring, and never `loose` (from_global_lift)
             lift_wide_consts<A>(lf);
         }
         if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
@@ -1061,6 +1079,7 @@ __global__ __launch_bounds__(256) void k_ntt_fwd_top_lift(const u64* __restrict_
     const ntt_limb_t L = LT[sel.idx[j]];
     lift_t lf;
     lf.qi = LT[sel.idx[i]].q; lf.half = lf.qi >> 1; lf.qj = L.q; lf.bj = L.br;
+    if (io.lift_unsigned) lf.qi = lf.half = ~0ull;
     const u64 col = (u64)(blockIdx.x % chunks) * blockDim.x + threadIdx.x;
     if (col >= stride) return;
     const u64* s = ct + ((size_t)((b * io.polys + io.polys - 1) * io.level + i) << logn);
@@ -1431,7 +1450,7 @@ __global__ __launch_bounds__(256) void k_ntt_perm(const u64* __restrict__ src, u
 struct ks_arg_t {
     int level, nw, special, polys;
     limb_sel_t w;                // working limbs: key limbs 0..level-1 (+ special prime)
-    tw_t pmul[TFHE_MAX_LIMBS];   // P mod q_j (special) for j < level
+    tw_t pinv[TFHE_MAX_LIMBS];   // P^-1 mod q_j (special) for j < level: the epilogue of the key sums in tfhe_matmul_diag (ks_keys_t::epi_x)
 };
 
 // S[b][s][j] = Σ_i evk[i][s'][w[j]] * D[b][i][j]  (NTT domain); s = 0 (c1) uses masked, s = 1 (c2) uses mask
@@ -1443,9 +1462,11 @@ struct ks_arg_t {
 struct ks_keys_t {
     int n;
     size_t s_stride;  // words of S per key
+    const u64* epi_x; // EPI kernels (tfhe_matmul_diag, evaluation-domain form): X [batch][2][level][N]; limb j < level of the sums
+                      // leaves as V = S P^-1 (+ X[b][0][j] for s = 0) instead of S (k_md_v folded into the store)
     const u64* key[TFHE_DOT_MAX];
 };
-template <int DCH>
+template <int DCH, bool EPI = false>
 __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, const u64* __restrict__ dig,
                                                    u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
                                                    int Lk, u32 n, u32 batch, u32 bsplit, u32 limb_mask, ks_keys_t K) {
@@ -1489,6 +1510,12 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
                 r1 = addmod(r1, barrett_reduce128(s1.lo, s1.hi, L.br), L.q);
                 r2 = addmod(r2, barrett_reduce128(s2.lo, s2.hi, L.br), L.q);
             }
+            if constexpr (EPI) {
+                if (i0 + DCH >= A.level && j < (u32)A.level) {
+                    r1 = addmod(shoup_full(r1, A.pinv[j], L.q), K.epi_x[(((size_t)b * 2) * A.level + j) * n + k], L.q);
+                    r2 = shoup_full(r2, A.pinv[j], L.q);
+                }
+            }
             *s1p = r1;
             *s2p = r2;
         }
@@ -1497,7 +1524,7 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
 
 // Same sums for working moduli below 2^52, two coefficients per thread (16-byte loads / stores) and carry-free
 // 26-bit-split accumulation (modarith.h acc52): the kernel is bound by the digit stream, not by the multiplier.
-template <int DCH>
+template <int DCH, bool EPI = false>
 __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk, const u64* __restrict__ dig,
                                                       u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
                                                       int Lk, u32 n, u32 batch, u32 bsplit, u32 limb_mask, ks_keys_t K) {
@@ -1551,6 +1578,16 @@ __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk
                 r1[v] = barrett_reduce128(lo, hi, br);
                 acc52_fold(s2[v], lo, hi);
                 r2[v] = barrett_reduce128(lo, hi, br);
+            }
+            if constexpr (EPI) {
+                if (i0 + DCH >= A.level && j < (u32)A.level) {
+                    const u64x2_t x = *(const u64x2_t*)(K.epi_x + (((size_t)b * 2) * A.level + j) * n + k);
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        r1[v] = addmod(shoup_full(r1[v], A.pinv[j], br.q), x[v], br.q);
+                        r2[v] = shoup_full(r2[v], A.pinv[j], br.q);
+                    }
+                }
             }
             *s1p = r1;
             *s2p = r2;
@@ -2184,6 +2221,135 @@ __global__ __launch_bounds__(256) void k_ks_rot_tail(const u64* __restrict__ T, 
                     v = addmod(v, a, q);
                 }
                 og[(size_t)j * n + m] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tfhe_matmul_diag with a special prime, evaluation-domain form (infer.jl:140-149 over rlwe_she.jl:315-347 and
+// modulusraising.jl:35-49).  With S' = sum_i NTT(digit_i) (.) key'_{r,i} the key sums of the UNROTATED digits against rotation
+// r's prepared key (all nw working limbs, NTT domain), the rotated ciphertext is
+//     rot_r = sigma_g( c_0 [s = 0] ) + floor-contraction( sigma_g( INTT(S') ) ),   contraction_j(x) = (x_j - [x_P]) P^-1 mod q_j
+// (k_ks_rot_tail).  sigma_g is a ring automorphism, so in the evaluation domain it is the pure permutation pi_g of
+// galois_ntt_pos -- no signs -- on every limb, and by linearity of NTT_j
+//     NTT_j(rot_r)[k] = ( S'_j[pi k] P^-1 + X0_j[pi k] )  -  P^-1 NTT_j( [ INTT_P( S'_P o pi ) ] mod q_j )[k],     X0 = NTT(c_0):
+// only the SPECIAL limb of every sum is inverse-transformed (after the permutation, so that the unsigned representative the
+// floor takes is the rotated polynomial's), its lift costs `level` forward transforms per sum -- which the coefficient-domain
+// path also spends, on the rotated ciphertext -- and the `level` inverse transforms per sum of that path are not needed.
+// Every step is exact modular arithmetic on canonical residues: the accumulated product is bit-identical.
+//   k_md_special_perm   P[grp]      = S'[grp][special] o pi_g            (XCD-cooperative gather, grp = (r * batch + b) * 2 + s)
+//   (inverse transform of P on the special limb)
+//   k_md_lift           U[grp][j]   = ([P[grp]] mod q_j) P^-1             (unsigned representative, crt.jl:215-220)
+//   (forward transforms of U; at N = 2^16 the lift is fused into their loads -- ntt_io_t::lift_unsigned -- and k_md_acc
+//   multiplies by P^-1 itself: USCALE)
+//   (V[grp][j] = S'[grp][j] P^-1 + X0[b][j] [s = 0] is what the key-sum kernels store for j < level: k_ks_inner<.., EPI>)
+//   k_md_acc            out[b][s][j][k] = diag_0[j][k] X[b][s][j][k] + sum_r diag_{r+1}[j][k] (V[grp][j][pi_r k] - U[grp][j][k])
+// The gathers are XCD-cooperative (one row per XCD at a time, as k_ks_rot_tail): a permutation uses every cache line of its
+// 8 N-byte window 16 times, so the window has to stay in one L2 until the row is done.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_md_special_perm(const u64* __restrict__ S, u64* __restrict__ P, rot_tail_arg_t G, u32 n, u32 nw,
+                                                          u32 level, u32 batch, u32 ngroups) {
+    const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    for (u32 grp = xcd; grp < ngroups; grp += 8u) {
+        const u64 g = G.g[(grp >> 1) / batch];
+        const u64* s = S + ((size_t)grp * nw + level) * n;
+        u64* d = P + (size_t)grp * n;
+        for (u32 m = slot * blockDim.x + threadIdx.x; m < n; m += nslot * blockDim.x) d[m] = s[galois_ntt_pos(m, g, n)];
+    }
+}
+// rows = ngroups * level, row = grp * level + j
+__global__ __launch_bounds__(256) void k_md_lift(const u64* __restrict__ P, u64* __restrict__ U, const ntt_limb_t* __restrict__ LT,
+                                                  limb_sel_t sel, rescale_arg_t ra, u32 n) {
+    const u32 row = blockIdx.x, level = (u32)sel.n, j = row % level, grp = row / level;
+    const ntt_limb_t L = LT[sel.idx[j]];
+    const u64* s = P + (size_t)grp * n;
+    u64* d = U + (size_t)row * n;
+    for (u32 i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x)
+        d[i] = shoup_full(barrett_reduce128(s[i], 0, L.br), ra.qlinv[j], L.q);
+}
+// out rows (b, s, j) = (b * 2 + s) * level + j; diag: [R+1][level][N].  One XCD takes the two rows (b, 0, j), (b, 1, j) at a time:
+// they share the diagonal words and the permuted positions, and the V windows in flight are the two rows of ONE rotation (a
+// version that requested four rotations at a time per coefficient ran slower than the plain loop: eight windows are the whole
+// L2).  The memory parallelism comes from KB coefficients per thread instead, with rotation t + 1 requested before rotation t
+// is accumulated.
+#ifndef TFHE_MD_KB
+#define TFHE_MD_KB 8
+#endif
+#ifndef TFHE_MD_SLOTS
+#define TFHE_MD_SLOTS 32   // workgroups per XCD (KB x SLOTS x 256 = 2^16: measured 63.7 k / 65.9 k / 66.9 k images/s at KB = 2 / 4 / 8)
+#endif
+template <bool USCALE>
+__global__ __launch_bounds__(256) void k_md_acc(const u64* __restrict__ X, const u64* __restrict__ V, const u64* __restrict__ U,
+                                                 const u64* __restrict__ diag, u64* __restrict__ out, const ntt_limb_t* __restrict__ LT,
+                                                 limb_sel_t sel, rot_tail_arg_t G, rescale_arg_t ra, u32 n, u32 nw, u32 nrot, u32 batch) {
+    constexpr int KB = TFHE_MD_KB;
+    const u32 level = (u32)sel.n;
+    const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3, stride = nslot * blockDim.x;
+    const size_t dstride = (size_t)level * n, gstride = (size_t)batch * 2;   // diagonal stride; groups per rotation
+    struct term_t { u64 v0[KB], v1[KB], u0[KB], u1[KB], d[KB]; };
+    for (u32 pr = xcd; pr < batch * level; pr += 8u) {
+        const u32 j = pr % level, b = pr / level;
+        const ntt_limb_t L = LT[sel.idx[j]];
+        const tw_t pinv = ra.qlinv[j];
+        int bits = 0;
+        while ((L.q >> bits) != 0) bits++;
+        const u32 chunk = bits >= 62 ? 1u : (62 - bits >= 6 ? 64u : (1u << (62 - bits)));   // products summed between two reductions
+        const size_t row0 = ((size_t)b * 2 * level + j) * n, row1 = row0 + (size_t)level * n;
+        const u64* dj = diag + (size_t)j * n;
+        for (u32 kb = slot * blockDim.x + threadIdx.x; kb < n; kb += stride * KB) {
+            u32 k[KB];
+#pragma unroll
+            for (int i = 0; i < KB; i++) k[i] = kb + (u32)i * stride < n ? kb + (u32)i * stride : kb;   // (a clamped lane repeats kb; not stored)
+            auto fetch = [&](u32 t, term_t& T) {
+                const size_t g0 = (size_t)t * gstride + (size_t)b * 2;
+                const u64 g = G.g[t];
+                const u64 *pv0 = V + (g0 * nw + j) * n, *pv1 = V + ((g0 + 1) * nw + j) * n;
+                const u64 *pu0 = U + (g0 * level + j) * n, *pu1 = U + ((g0 + 1) * level + j) * n, *pd = dj + (size_t)(t + 1) * dstride;
+#pragma unroll
+                for (int i = 0; i < KB; i++) {
+                    const u32 kk = galois_ntt_pos(k[i], g, n);
+                    T.v0[i] = pv0[kk]; T.v1[i] = pv1[kk]; T.u0[i] = pu0[k[i]]; T.u1[i] = pu1[k[i]]; T.d[i] = pd[k[i]];
+                }
+            };
+            acc128 a0[KB], a1[KB];
+#pragma unroll
+            for (int i = 0; i < KB; i++) {
+                const u64 d0 = dj[k[i]];
+                a0[i] = acc128{0, 0}; a1[i] = acc128{0, 0};
+                acc_mac(a0[i], X[row0 + k[i]], d0);
+                acc_mac(a1[i], X[row1 + k[i]], d0);
+            }
+            u32 pend = 1;
+            term_t cur;
+            fetch(0, cur);
+            for (u32 t = 0; t < nrot; t++) {
+                term_t nxt;
+                fetch(t + 1 < nrot ? t + 1 : t, nxt);
+                if (pend == chunk) {
+#pragma unroll
+                    for (int i = 0; i < KB; i++) {
+                        a0[i] = acc128{barrett_reduce128(a0[i].lo, a0[i].hi, L.br), 0};
+                        a1[i] = acc128{barrett_reduce128(a1[i].lo, a1[i].hi, L.br), 0};
+                    }
+                    pend = 0;
+                }
+#pragma unroll
+                for (int i = 0; i < KB; i++) {
+                    u64 w0 = cur.u0[i], w1 = cur.u1[i];
+                    if constexpr (USCALE) { w0 = shoup_full(w0, pinv, L.q); w1 = shoup_full(w1, pinv, L.q); }
+                    acc_mac(a0[i], submod(cur.v0[i], w0, L.q), cur.d[i]);
+                    acc_mac(a1[i], submod(cur.v1[i], w1, L.q), cur.d[i]);
+                }
+                pend++;
+                cur = nxt;
+            }
+#pragma unroll
+            for (int i = 0; i < KB; i++) {
+                if (kb + (u32)i * stride < n) {
+                    out[row0 + k[i]] = barrett_reduce128(a0[i].lo, a0[i].hi, L.br);
+                    out[row1 + k[i]] = barrett_reduce128(a1[i].lo, a1[i].hi, L.br);
+                }
             }
         }
     }

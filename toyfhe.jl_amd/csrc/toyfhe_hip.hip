@@ -478,6 +478,12 @@ bool bfv_core_fusable(const tfhe_ctx* c, const limb_sel_t& sel) { return c->vari
 // forward transforms + tensor + inverse transforms of one BFV multiplication chunk in one kernel (fp64 policy, N = 2^12 .. 2^14:
 // the reference's own BFV tests run at 2^11 - 2^12, test/bfv_crt.jl:8, and its MNIST parameters at 2^13, infer.jl:97);
 // *done = false when the configuration is not covered.  scratch: one row per workgroup.
+#ifndef TFHE_GRID_MULT_CORE  // workgroups per CU slot in the grids of the two fused kernels (> 1: the dispatcher balances the items)
+#define TFHE_GRID_MULT_CORE 1u
+#endif
+#ifndef TFHE_GRID_MULT_KS
+#define TFHE_GRID_MULT_KS 1u
+#endif
 template <int LOGB>
 static int launch_bfv_core_fused_n(tfhe_ctx* c, const u64* Ea, const u64* Eb, u64* T, u64* scratch, int64_t nct, const limb_sel_t& sel,
                                    const core_alt_t& alt, bool out_double) {
@@ -493,7 +499,7 @@ static int launch_bfv_core_fused_n(tfhe_ctx* c, const u64* Ea, const u64* Eb, u6
     }
     const unsigned items = (unsigned)(nct * sel.n);
     // one 512-thread workgroup fills a CU at 2^14; the 256-thread workgroups of the smaller rings leave room for a second one
-    const unsigned grid = std::min(items, (LOGB == 14 ? 1u : 2u) * (unsigned)c->num_cus);
+    const unsigned grid = std::min(items, (LOGB == 14 ? 1u : 2u) * (unsigned)c->num_cus * TFHE_GRID_MULT_CORE);
     prof_begin(c, (int64_t)items * 7);  // limb transforms inside this launch: 4 forward + 3 inverse per item
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1 << LOGT), lds, c->stream, Ea, Eb, T, scratch, c->limbs_dev, sel, items, alt);
     prof_end(c);
@@ -1004,11 +1010,58 @@ static int ks_digits_fwd(tfhe_ctx* c, const ks_arg_t& A, const u64* ct, u64* dig
     return TFHE_OK;
 }
 
+// tfhe_matmul_diag, evaluation-domain form: U[grp][j] = NTT_j( [P[grp]] mod q_j ) (x P^-1 unless *scaled comes back false) for
+// the `groups` special-limb rows P (coefficient domain, canonical) and the limbs j of `sl`.  At N = 2^16 the lift rides on the
+// forward transforms' loads (ntt_io_t::lift_unsigned: k_ntt_fwd_quad for the fp64-size limbs, k_ntt_fwd_top_lift + the u64 block
+// kernels for the others) and the factor P^-1 is left to k_md_acc; otherwise k_md_lift writes the scaled lifts to `LF` and plain
+// transforms follow.
+static int md_lift_fwd(tfhe_ctx* c, const ks_arg_t& A, const limb_sel_t& sl, const rescale_arg_t& ra, const u64* P, u64* LF, u64* U,
+                       int64_t groups, bool* scaled) {
+    const int level = A.level;
+    const u32 n = (u32)c->N;
+    const int64_t rows = groups * level;
+    const u32 tmask = mask_of(level, [&](int j) { return c->limbs_host[sl.idx[j]].Wd != nullptr; });   // fp64-size target limbs
+    const u32 tall = mask_all(level);
+    const bool special_fp = c->limbs_host[A.w.idx[level]].Wd != nullptr;
+    static const bool unfused = getenv("TFHE_MD_LIFT_UNFUSED") && getenv("TFHE_MD_LIFT_UNFUSED")[0] == '1';
+    if (!unfused && c->logN == 16 && c->variant == 0 && level <= 32 && (rows << 2) <= 0x7fffffffll && (((uintptr_t)P | (uintptr_t)U) & 15u) == 0) {
+        ntt_io_t io = io_plain();
+        io.mode = 1; io.level = 1; io.nw = (u32)level; io.polys = 1; io.lift_unsigned = 1;
+        int rc;
+        if (tmask) {   // the fp64-size limbs: one kernel per row pair (ArithFpWide reads a source above 2^52 in two halves)
+            ntt_io_t a = io;
+            a.limb_mask = tmask == tall ? 0u : tmask;
+            rc = run_ntt_large(c, false, P, U, rows, sl, a, &a, true, !special_fp);
+            if (rc) return rc;
+        }
+        if (tmask != tall) {   // the larger limbs: lift fused into the top stages (into the transform scratch), then the u64 block kernels
+            void* tmp = nullptr;
+            rc = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
+            if (rc) return rc;
+            ntt_io_t w = io;
+            w.limb_mask = tmask ? (tall & ~tmask) : 0u;
+            const dim3 tg((unsigned)((((c->N >> 2) + 255) / 256) * rows));
+            hipLaunchKernelGGL(k_ntt_fwd_top_lift<2>, tg, dim3(256), 0, c->stream, P, (u64*)tmp, c->limbs_dev, sl, c->logN, w);
+            HIP_TRY(hipGetLastError());
+            ntt_io_t ib = io_plain();
+            ib.limb_mask = w.limb_mask;
+            rc = launch_block_fwd<ArithInt, 14>(c, (const u64*)tmp, U, rows, sl, 2, ib);
+            if (rc) return rc;
+        }
+        *scaled = false;
+        return TFHE_OK;
+    }
+    hipLaunchKernelGGL(k_md_lift, row_grid((unsigned)rows, (size_t)c->N), dim3(256), 0, c->stream, P, LF, c->limbs_dev, sl, ra, n);
+    HIP_TRY(hipGetLastError());
+    *scaled = true;
+    return run_ntt(c, false, LF, U, rows, sl);
+}
+
 static int do_galois(tfhe_ctx* c, const u64* src, u64* dst, u64 g, int64_t rows, const limb_sel_t& sel);
 // S_s = sum_i evk_{i,s} (.) digit_i over the working limbs (NTT domain), S: [batch][2][nw][N]
 // keys != nullptr: `nkeys` keys against the same digits in one launch, key r writing S + r * batch*2*nw*N (tfhe_matmul_diag)
 static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, const u64* dig, u64* S, int64_t batch,
-                           const uint64_t* const* keys = nullptr, int nkeys = 0) {
+                           const uint64_t* const* keys = nullptr, int nkeys = 0, const u64* epi_x = nullptr) {
     const int nw = A.nw;
     ks_keys_t K;
     memset(&K, 0, sizeof K);
@@ -1017,12 +1070,14 @@ static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* ev
         K.s_stride = (size_t)batch * 2 * nw * (size_t)c->N;
         for (int r = 0; r < nkeys; r++) K.key[r] = keys[r];
         evk = keys[0];
+        K.epi_x = epi_x;
     }
     const unsigned gy = keys ? (unsigned)nkeys : 1u;
     const u32 n = (u32)c->N;
     const unsigned gx = (n + 255) / 256;
     // enough workgroups to fill the chip: split the batch into slices (the key is re-read once per slice)
-    const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx - 1) / (nw * gx)));
+    // (several keys in one launch multiply the grid by gy)
+    const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx * gy - 1) / (nw * gx * gy)));
     // working limbs below 2^52: the two-coefficient, carry-free kernel; the others: the generic one (more than 32 working
     // limbs: all or nothing, see mask_of)
     u32 nmask = mask_of(nw, [&](int j) { return (c->limbs_host[A.w.idx[j]].q >> 52) == 0; });
@@ -1030,12 +1085,14 @@ static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* ev
     if (n % 2 != 0) nmask = 0;
     if (nmask) {
         const unsigned gx2 = (n / 2 + 255) / 256;
-        const unsigned bs2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx2 - 1) / (nw * gx2)));
-        hipLaunchKernelGGL(k_ks_inner_n2<8>, dim3((unsigned)nw * gx2 * bs2, gy), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2,
+        const unsigned bs2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx2 * gy - 1) / (nw * gx2 * gy)));
+        auto kn = epi_x ? k_ks_inner_n2<8, true> : k_ks_inner_n2<8, false>;
+        hipLaunchKernelGGL(kn, dim3((unsigned)nw * gx2 * bs2, gy), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2,
                            nmask == amask ? 0u : nmask, K);
     }
     if (nmask != amask) {
-        hipLaunchKernelGGL(k_ks_inner<8>, dim3((unsigned)nw * gx * bsplit, gy), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit,
+        auto kg = epi_x ? k_ks_inner<8, true> : k_ks_inner<8, false>;
+        hipLaunchKernelGGL(kg, dim3((unsigned)nw * gx * bsplit, gy), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit,
                            nmask ? (amask & ~nmask) : 0u, K);
     }
     HIP_TRY(hipGetLastError());
@@ -1151,7 +1208,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
                 if (rc) return rc;
                 fattr_set = true;
             }
-            const unsigned grid = std::min(items, (unsigned)c->num_cus);
+            const unsigned grid = std::min(items, (unsigned)c->num_cus * TFHE_GRID_MULT_KS);
             prof_begin(c, (int64_t)items * (level + 2));  // limb transforms inside this launch: `level` forward + 2 inverse per item
             hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, special ? S : out, c->limbs_dev, A, Lk, items);
             prof_end(c);
@@ -1401,13 +1458,19 @@ int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
     memset(&ra, 0, sizeof ra);
     if (special) {
         const u64 P = c->q[Lk - 1];
-        for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+        for (int j = 0; j < level; j++) A.pinv[j] = ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
     }
     rot_tail_arg_t G;
     memset(&G, 0, sizeof G);
     for (int r = 0; r < R; r++) G.g[r] = galois[r];
+    // With a special prime the rotations are finished in the evaluation domain (k_md_*: only the special limb of every key sum is
+    // inverse-transformed); TFHE_MD_COEFF=1 keeps the coefficient-domain tail (k_ks_rot_tail) for comparisons.
+    static const bool md_coeff = getenv("TFHE_MD_COEFF") && getenv("TFHE_MD_COEFF")[0] == '1';
+    const bool eval_form = special && R > 0 && !md_coeff;
     // workspace per ciphertext: digits (level nw rows) + S / T (R 2 nw) + rotated ciphertexts (R 2 level) + the ciphertext's own transform (2 level)
-    const size_t per_ct = ((size_t)level * nw + (size_t)R * 2 * nw + (size_t)R * 2 * level + (size_t)2 * level) * N * 8;
+    // (+ evaluation-domain form: the lifted special limbs before their transforms (R 2 level) and the special limbs themselves (R 2))
+    const size_t per_ct = ((size_t)level * nw + (size_t)R * 2 * nw + (size_t)R * 2 * level + (size_t)2 * level +
+                           (eval_form ? (size_t)R * 2 * level + (size_t)R * 2 : 0)) * N * 8;
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)((8192ull << 20) / per_ct)}));
     const size_t ntt_rows = (size_t)chunk * std::max<size_t>({(size_t)level * nw, (size_t)R * 2 * nw, (size_t)2 * level});
     const size_t ntt_tmp = c->logN > 14 ? ntt_rows * N * 8 : 0;
@@ -1421,6 +1484,33 @@ int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
     for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
         const int64_t nb = std::min(chunk, batch - b0);
         const u64* cin = ct + (size_t)b0 * polys * level * N;
+        if (eval_form) {
+            u64* const U = ROT;                                  // [R][nb][2][level][N]
+            u64* const LF = X + (size_t)chunk * 2 * level * N;   // lifted special limbs, untransformed (same shape)
+            u64* const PB = LF + (size_t)chunk * R * 2 * level * N;   // [R][nb][2][N]
+            const u32 groups = (u32)((int64_t)R * nb * 2);
+            rc = run_ntt(c, false, cin, X, nb * 2 * level, sl);
+            if (rc) return rc;
+            rc = ks_digits_fwd(c, A, cin, dig, nb);
+            if (rc) return rc;
+            rc = ks_inner_launch(c, A, Lk, nullptr, dig, S, nb, evks, R, X);   // limbs j < level leave as V = S' P^-1 + X0 [s = 0]
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_md_special_perm, dim3(8 * TFHE_ROT_TAIL_SLOTS), dim3(256), 0, c->stream, S, PB, G, n, (u32)nw, (u32)level, (u32)nb, groups);
+            HIP_TRY(hipGetLastError());
+            limb_sel_t sp;
+            sp.n = 1;
+            sp.idx[0] = Lk - 1;
+            rc = run_ntt(c, true, PB, PB, (int64_t)groups, sp);
+            if (rc) return rc;
+            bool scaled = true;
+            rc = md_lift_fwd(c, A, sl, ra, PB, LF, U, (int64_t)groups, &scaled);
+            if (rc) return rc;
+            auto acc = scaled ? k_md_acc<false> : k_md_acc<true>;
+            hipLaunchKernelGGL(acc, dim3(8 * TFHE_MD_SLOTS), dim3(256), 0, c->stream, X, S, U, diags, out + (size_t)b0 * 2 * level * N, c->limbs_dev, sl,
+                               G, ra, n, (u32)nw, (u32)R, (u32)nb);
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         if (R) {
             rc = ks_digits_fwd(c, A, cin, dig, nb);
             if (rc) return rc;
