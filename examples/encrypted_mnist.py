@@ -113,7 +113,7 @@ def load_model(path=GOLDEN_MODEL):
     return m
 
 
-def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=False, repeat=1, fused=False, return_logits=False):
+def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=False, repeat=1, fused=False, return_logits=False, stats=None):
     """`batches` = K ciphertext sets evaluated together (K * B images): every ring element carries a leading batch dimension
     of K, so each device call covers K ciphertexts (the batch the engine shards across GPUs)."""
     N = 1 << logn
@@ -182,6 +182,8 @@ def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=Fal
       got = dec.reshape(K, 64, B)[:, :10].transpose(1, 0, 2).reshape(10, K * B)
       t_eval = time.perf_counter() - t0
     err = float(np.abs(got - want).max())
+    if stats is not None:   # (tools/bench_configs.py)
+        stats.update(images=K * B, eval_s=t_eval, setup_s=t_setup, images_per_s=K * B / t_eval)
     if verbose:
         print(f"N=2^{logn}, {K} x {B} images: setup {t_setup:.2f} s, encrypted evaluation {t_eval:.2f} s = {K * B / t_eval:.0f} images/s "
               f"(49 encrypted inputs, 5 x 63 {'hoisted ' if hoisted else ''}rotations, 5 relinearisations per ciphertext set"

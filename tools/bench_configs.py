@@ -116,6 +116,21 @@ def ntt_case(name, N, qs, polys):
                     "inv_frac_of_hbm_peak": gb / t_i / HBM_PEAK_GBS})
 
 
+def mnist_case(name, logn, sets):
+    """BASELINE.json configs[4] end to end: the encrypted CNN of examples/encrypted_mnist.py (infer.jl's circuit on the reference's
+    trained weights, synthetic images) with hoisted rotations and the fused diagonal products; third pass, weights encoded by the
+    first.  The logits are checked against the float64 model inside run()."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import encrypted_mnist as em
+    st = {}
+    err, rng_, agree = em.run(logn, 0, verbose=False, batches=sets, hoisted=True, repeat=3, fused=True, stats=st)
+    assert err < 5e-3 * max(1.0, rng_) and agree > 0.99, name + ": logits differ from the float64 model"
+    print(f"{name}: {st['images']} images in {st['eval_s'] * 1e3:.1f} ms = {st['images_per_s']:.0f} images/s  (max logit error {err:.2e}, argmax agreement {agree})")
+    RECORDS.append({"config": name, "N": 1 << logn, "ciphertext_sets": sets, "images": st["images"], "images_per_s": st["images_per_s"],
+                    "ms_per_pass": st["eval_s"] * 1e3, "max_logit_error": err, "logit_range": rng_, "argmax_agreement": agree,
+                    "oracle_checked": "float64 model (infer.jl:55-88)", "includes": "host (Python) time between launches"})
+
+
 def run(scale=1, out=None, only=None):
     """All cases; returns the list of records (each case asserts one ciphertext against the oracle before it is timed).  A case that
     fails is recorded as {"config": ..., "error": ...} and does not stop the others."""
@@ -146,6 +161,7 @@ def run(scale=1, out=None, only=None):
     N = 1 << 14
     guarded(ntt_case, "N=2^14 60-bit primes", N, chain(2**60 + 1, 8, N), max(8, 1024 // scale))
     guarded(ntt_case, "N=2^14 50-bit primes", N, chain(2**50 + 1, 8, N), max(8, 1024 // scale))
+    guarded(mnist_case, "cfg#5 encrypted MNIST inference N=2^16, infer.jl ring (examples/encrypted_mnist.py)", 16, max(1, 16 // scale))
     return list(RECORDS)
 
 
