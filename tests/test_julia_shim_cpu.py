@@ -120,7 +120,7 @@ def test_ccalls_agree_with_the_ctypes_table_the_tests_run_through():
 
 
 JULIA_BASE = set("""
-get get! haskey push! map tuple length size axes zeros zero collect reinterpret convert error throw finalizer unsafe_string
+get get! haskey all isempty push! map tuple length size axes zeros zero collect reinterpret convert error throw finalizer unsafe_string
 enumerate fieldtypes round ispow2 trailing_zeros ndigits numerator denominator big invoke typeof eltype isa new similar string
 Ref Dict IdDict Vector Matrix UInt64 UInt32 Int32 Int64 Cint Float64 ComplexF64 Rational BigInt AssertionError OutOfMemoryError
 OffsetArray StructArray Ptr in ccall tuple first last min max setindex! getindex sel x HipVector Int

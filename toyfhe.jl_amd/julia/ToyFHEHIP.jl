@@ -390,6 +390,32 @@ function rotate_many(gks::Vector{<:ToyFHE.GaloisKey}, c::CipherText{Enc,P,<:Ring
     end
 end
 
+# diags[1] .* c + sum_k diags[k+1] .* rotate(gks[k], c) -- the diagonal matrix-vector product of infer.jl:140-149 /
+# test/ckks_matmul.jl:33-41 -- in one device call (tfhe_matmul_diag): hoisted rotations, with a special prime finished in the
+# evaluation domain, accumulation included; the result is in the NTT domain like that of `dot`.  diags: plaintext elements of c's
+# ring (one polynomial each, shared by the batch).  Same words as rotate_many -> coeffs_dual -> dot.
+function matmul_diag(gks::Vector{<:ToyFHE.GaloisKey}, diags::Vector{<:RingElement{ℛ,T,<:HipVector}},
+                     c::CipherText{Enc,P,<:RingElement{ℛ,T,<:HipVector}}) where {Enc,P,ℛ,T}
+    @assert length(c.cs) == 2 && !isempty(gks) && length(diags) == length(gks) + 1
+    ek1 = gks[1].key; keyring = NTT.ring(ek1.key[1].mask); Lk = nlimbs(eltype(keyring)); level = nlimbs(T); cnt = batchsize(c)
+    ctx = hipring(keyring); ct = pack(ctx, c); n = degree(ℛ); nrot = length(gks)
+    packed = HipVector[pack(gk.key) for gk in gks]
+    dparts = HipVector[coeffs_dual(d).parent for d in diags]
+    all(d -> d.count == 1, dparts) || throw(ToyFHE.UsageError("matmul_diag: one polynomial per diagonal"))
+    dg = HipVector{T}(level, n, nrot + 1); on(ctx, (dg,), (dparts...,))
+    GC.@preserve dparts dg for (k, d) in enumerate(dparts)                    # dg: [nrot + 1][level][N]
+        check(ccall((:tfhe_memcpy_d2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+              ctx.handle, dg.ptr + 8 * (k - 1) * level * n, d.ptr, 8 * level * n))
+    end
+    out = HipVector{T}(2 * level, n, cnt); on(ctx, (out,), (ct, dg, packed...))
+    keys = Ptr{UInt64}[k.ptr for k in packed]; gs = UInt64[gk.galois_element for gk in gks]
+    GC.@preserve packed ct dg out check(ccall((:tfhe_matmul_diag, lib), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Ptr{UInt64}}, Cint, Ptr{UInt64}, Cint, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Int64),
+                ctx.handle, Lk, level, ek1.params isa ModulusRaised ? 1 : 0, keys, length(ek1.key), gs, nrot,
+                dg.ptr, ct.ptr, out.ptr, cnt))
+    CipherText{Enc}(c.params, unpack(ctx, out, ℛ, 2; dual=true))
+end
+
 # ---- CKKS encode / decode (ckksencoding.jl:56-97) on the device --------------------------------------------------------
 # denom = mant * 2^exp2 with a 64-bit mant (exact for 2^k and for integers below 2^64 times 2^k; to 2^-63 otherwise)
 function scale_parts(denom)
