@@ -255,6 +255,38 @@ def test_matmul_diag_is_bit_identical_to_rotate_many_and_dot(logn, bits, n_rot, 
     assert all(np.array_equal(a.to_numpy("dual"), b.to_numpy("dual")) for a, b in zip(only.cs, w0.cs))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_matmul_diag_random_small_shapes(seed):
+    """Random small rings (N = 2^4 .. 2^9, one to four ciphertext limbs of 30-60 bits, with and without the special prime, one
+    to six rotations, single and batched): tfhe_matmul_diag against rotate_many + dot_plain, word for word -- the
+    evaluation-domain form at every limb count (a single limb, odd and even counts: both masked walks) and the k_md_lift path."""
+    rs = np.random.default_rng(900 + seed)
+    logn = int(rs.integers(4, 10)); N = 1 << logn
+    L = int(rs.integers(1, 5)); raised = bool(rs.integers(0, 4))           # mostly with the special prime
+    qs, used = [], set()
+    for _ in range(L + (1 if raised else 0)):
+        q = tf.nextprime(2 ** int(rs.choice([30, 40, 50, 60])) + 1, 1, 2 * N)
+        while q in used:
+            q = tf.nextprime(q + 2 * N, 1, 2 * N)
+        used.add(q); qs.append(q)
+    params = tf.CKKSParams(tf.NegacyclicRing(N, qs), 0, 3.2)
+    if raised:
+        params = tf.ModulusRaised(params)
+    rng = tf.DeviceRng(7000 + seed)
+    kp = tf.keygen(rng, params)
+    n_rot = int(rs.integers(1, 7)); batch = [None, 2, 3][int(rs.integers(0, 3))]
+    shape = (N // 2,) if batch is None else (batch, N // 2)
+    scale = 2**20
+    c = tf.encrypt(rng, kp, tf.ckks_encode(rs.normal(0, 1, shape).astype(complex), params.R_cipher(), scale), scale=scale)
+    gks = [tf.keygen_galois(rng, kp.priv, steps=int(k)) for k in rs.choice(np.arange(1, N // 2), n_rot, replace=False)]
+    dv = rs.normal(0, 1, (n_rot + 1, N // 2)).astype(complex)
+    singles = [tf.ckks_encode(dv[k], params.R_cipher(), scale) for k in range(n_rot + 1)]
+    want = tf.CipherText.dot_plain([c] + list(tf.rotate_many(gks, c)), [d if batch is None else d.broadcast_to(batch) for d in singles])
+    got = tf.matmul_diag(gks, singles, c)
+    for a, b in zip(got.cs, want.cs):
+        assert np.array_equal(a.to_numpy("dual"), b.to_numpy("dual")), (logn, qs, raised, n_rot, batch)
+
+
 def test_lincomb_equals_the_sum_of_scalar_products():
     """CipherText.lincomb (tfhe_lincomb: the 49 scalar-weighted terms of a convolution channel, infer.jl:127-129, in one pass per
     component) against sum(c.mul_plain(w)) word for word, in both domains, single and batched."""
