@@ -159,10 +159,12 @@ def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=Fal
     for rep in range(repeat):
       t0 = time.perf_counter()
       conved = []
+      if fused:        # the 4 x 49 scalar-weighted terms in one device pass per component over the 49 inputs (tfhe_lincomb_many)
+          accs = tf.CipherText.lincomb_many([C[i][j] for i in range(7) for j in range(7)],
+                                            [[float(model["conv_w"][i, j, ch]) for i in range(7) for j in range(7)] for ch in range(4)])
       for ch in range(4):
-          if fused:    # the 49 scalar-weighted terms of a channel in one device pass per component (tfhe_lincomb)
-              acc = tf.CipherText.lincomb([C[i][j] for i in range(7) for j in range(7)],
-                                          [float(model["conv_w"][i, j, ch]) for i in range(7) for j in range(7)])
+          if fused:
+              acc = accs[ch]
           else:
               acc = None
               for i in range(7):

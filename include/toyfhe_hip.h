@@ -129,6 +129,12 @@ int tfhe_dot(tfhe_ctx *ctx, const uint64_t *acc, const uint64_t *const *a, const
  * device pointers; n_terms <= 64.  Exact: the canonical residues of the term-by-term sum. */
 int tfhe_lincomb(tfhe_ctx *ctx, const uint64_t *scalars, const uint64_t *const *a, int n_terms, uint64_t *dst, int64_t count, int limbs,
                  const int32_t *limb_idx);
+/* n_out such sums of the SAME operands in one pass over them -- the output channels of a convolution layer, infer.jl:127-131 (each of
+ * the 4 channels weighs the same 49 encrypted inputs): dst[o] = sum_k scalars[o][k] * a[k].  scalars: HOST array
+ * [n_out][n_terms][limbs] of residues; dst: host array of n_out device pointers ([count][limbs][N] each, distinct from the
+ * operands); n_terms <= 64.  Same words as n_out calls of tfhe_lincomb. */
+int tfhe_lincomb_many(tfhe_ctx *ctx, const uint64_t *scalars, const uint64_t *const *a, int n_terms, uint64_t *const *dst, int n_out,
+                      int64_t count, int limbs, const int32_t *limb_idx);
 /* scalar_mul (pow2_cyc_rings.jl:177-185): scalar given as residues scal[j] mod q_{limb_idx[j]} (host array) */
 int tfhe_scalar_mul(tfhe_ctx *ctx, const uint64_t *scal, const uint64_t *a, uint64_t *dst, int64_t count, int limbs, const int32_t *limb_idx);
 

@@ -315,5 +315,16 @@ def test_lincomb_equals_the_sum_of_scalar_products():
         got = tf.CipherText.lincomb(cts, ws)
         for a, b in zip(got.cs, want.cs):
             assert a.primal is None and np.array_equal(a.to_numpy("dual"), b.to_numpy("dual"))
+        # several sums of the same operands in one pass (tfhe_lincomb_many: 4 per launch, so 6 rows take two) = one call per row
+        rows = [ws] + [list(nrng.normal(0, 0.3, 49)) for _ in range(5)]
+        many = tf.CipherText.lincomb_many(cts, rows)
+        assert len(many) == 6
+        for row, m in zip(rows, many):
+            one = tf.CipherText.lincomb(cts, row)
+            assert m.scale == one.scale
+            for a, b in zip(m.cs, one.cs):
+                assert np.array_equal(a.to_numpy("dual"), b.to_numpy("dual"))
+    with pytest.raises(AssertionError):
+        tf.CipherText.lincomb_many(cts, [ws, ws[:-1]])
     with pytest.raises(AssertionError):
         tf.CipherText.lincomb(cts, ws[:-1])

@@ -1257,6 +1257,42 @@ __global__ __launch_bounds__(256) void k_lincomb(dot_arg_t D, const u64* __restr
     }
 }
 
+// NO such sums of the SAME operands in one pass (the output channels of a convolution layer, infer.jl:127-131: each channel
+// weighs the same 49 encrypted inputs): every operand word is read once for all outputs.  scal: [NO][K][limbs]; dst: NO rows sets.
+struct lincomb_out_t {
+    u64* dst[4];
+};
+template <int NO>
+__global__ __launch_bounds__(256) void k_lincomb_many(dot_arg_t D, const u64* __restrict__ scal, lincomb_out_t O,
+                                                       const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 n) {
+    const u32 row = blockIdx.x, j = row % (u32)sel.n;
+    const ntt_limb_t L = LT[sel.idx[j]];
+    const size_t base = (size_t)row * n, ostride = (size_t)D.n * sel.n;
+    int bits = 0;
+    while ((L.q >> bits) != 0) bits++;
+    const int chunk = bits >= 62 ? 1 : (62 - bits >= 6 ? 64 : (1 << (62 - bits)));   // products summed between two reductions
+    for (u32 i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
+        u64 r[NO];
+#pragma unroll
+        for (int o = 0; o < NO; o++) r[o] = 0;
+        for (int k0 = 0; k0 < D.n; k0 += chunk) {
+            acc128 s[NO];
+#pragma unroll
+            for (int o = 0; o < NO; o++) s[o] = acc128{r[o], 0};
+            const int k1 = k0 + chunk < D.n ? k0 + chunk : D.n;
+            for (int k = k0; k < k1; k++) {
+                const u64 x = D.a[k][base + i];
+#pragma unroll
+                for (int o = 0; o < NO; o++) acc_mac(s[o], x, scal[(size_t)o * ostride + (size_t)k * sel.n + j]);
+            }
+#pragma unroll
+            for (int o = 0; o < NO; o++) r[o] = barrett_reduce128(s[o].lo, s[o].hi, L.br);
+        }
+#pragma unroll
+        for (int o = 0; o < NO; o++) O.dst[o][base + i] = r[o];
+    }
+}
+
 // Diagonal matrix-vector product, accumulation step: out[b][s][j] = diag[0][j] (.) X[b][s][j] + sum_r diag[r+1][j] (.) ROT[r][b][s][j]
 // (NTT domain; the loop `result += rotated_k * diagonal_k` of infer.jl:140-149 / test/ckks_matmul.jl:33-41 over all terms in
 // one pass: the canonical residues of the term-by-term sum).  diag: [R+1][limbs][N], shared by the batch.

@@ -843,6 +843,52 @@ int tfhe_lincomb(tfhe_ctx* c, const uint64_t* scalars, const uint64_t* const* a,
     return TFHE_OK;
 }
 
+int tfhe_lincomb_many(tfhe_ctx* c, const uint64_t* scalars, const uint64_t* const* a, int n_terms, uint64_t* const* dst, int n_out, int64_t count,
+                      int limbs, const int32_t* idx) {
+    if (!c || !scalars || !a || !dst) return fail(TFHE_E_BADARG, "null argument");
+    if (n_terms < 1 || n_out < 1) return fail(TFHE_E_BADARG, "tfhe_lincomb_many needs at least one term and one output");
+    if (n_terms > TFHE_DOT_MAX) return fail(TFHE_E_UNSUPPORTED, "tfhe_lincomb_many takes at most %d terms per call", TFHE_DOT_MAX);
+    limb_sel_t sel;
+    int rc = make_sel(c, limbs, idx, &sel);
+    if (rc) return rc;
+    if (count < 0) return fail(TFHE_E_BADARG, "negative count");
+    for (int k = 0; k < n_terms; k++)
+        if (!a[k]) return fail(TFHE_E_BADARG, "null operand %d", k);
+    for (int o = 0; o < n_out; o++)
+        if (!dst[o]) return fail(TFHE_E_BADARG, "null output %d", o);
+    const size_t per_out = (size_t)n_terms * limbs;
+    for (int o = 0; o < n_out; o++)
+        for (int k = 0; k < n_terms; k++)
+            for (int j = 0; j < limbs; j++)
+                if (scalars[(size_t)o * per_out + (size_t)k * limbs + j] >= c->q[sel.idx[j]])
+                    return fail(TFHE_E_BADARG, "scalar of output %d, term %d, limb %d is not a residue", o, k, j);
+    if (count == 0) return TFHE_OK;
+    void* dsc = nullptr;
+    hipError_t e = devalloc::alloc((size_t)n_out * per_out * 8, &dsc);
+    if (e != hipSuccess) return fail(TFHE_E_NOMEM, "hipMalloc(%zu): %s", (size_t)n_out * per_out * 8, hipGetErrorString(e));
+    hipError_t le = hipMemcpyAsync(dsc, scalars, (size_t)n_out * per_out * 8, hipMemcpyHostToDevice, c->stream);   // pageable source: staged before the call returns
+    dot_arg_t D;
+    D.n = n_terms;
+    for (int k = 0; k < n_terms; k++) { D.a[k] = a[k]; D.b[k] = nullptr; }
+    const dim3 grid = row_grid((unsigned)(count * limbs), (size_t)c->N);
+    for (int o0 = 0; o0 < n_out && le == hipSuccess; o0 += 4) {   // four outputs per pass over the operands
+        const int no = std::min(4, n_out - o0);
+        lincomb_out_t O;
+        for (int o = 0; o < 4; o++) O.dst[o] = o < no ? dst[o0 + o] : nullptr;
+        const u64* sc = (const u64*)dsc + (size_t)o0 * per_out;
+        switch (no) {
+            case 1: hipLaunchKernelGGL(k_lincomb_many<1>, grid, dim3(256), 0, c->stream, D, sc, O, c->limbs_dev, sel, (u32)c->N); break;
+            case 2: hipLaunchKernelGGL(k_lincomb_many<2>, grid, dim3(256), 0, c->stream, D, sc, O, c->limbs_dev, sel, (u32)c->N); break;
+            case 3: hipLaunchKernelGGL(k_lincomb_many<3>, grid, dim3(256), 0, c->stream, D, sc, O, c->limbs_dev, sel, (u32)c->N); break;
+            default: hipLaunchKernelGGL(k_lincomb_many<4>, grid, dim3(256), 0, c->stream, D, sc, O, c->limbs_dev, sel, (u32)c->N); break;
+        }
+        le = hipGetLastError();
+    }
+    devalloc::release(dsc);   // parked until the launches above have run
+    if (le != hipSuccess) return fail(TFHE_E_HIP, "k_lincomb_many: %s", hipGetErrorString(le));
+    return TFHE_OK;
+}
+
 int tfhe_tensor(tfhe_ctx* c, const uint64_t* a, const uint64_t* b, uint64_t* out, int64_t batch, int limbs, const int32_t* idx) {
     if (!c || !a || !b || !out) return fail(TFHE_E_BADARG, "null argument");
     limb_sel_t sel;

@@ -124,6 +124,7 @@ def lib():
         "tfhe_rotate_many": [vp, i32, i32, i32, C.POINTER(vp), i32, i32, u64p, i32, vp, vp, i64],
         "tfhe_galois_key_prepare": [vp, i32, i32, u64, vp, vp],
         "tfhe_matmul_diag": [vp, i32, i32, i32, C.POINTER(vp), i32, u64p, i32, vp, vp, vp, i64],
+        "tfhe_lincomb_many": [vp, u64p, C.POINTER(vp), i32, C.POINTER(vp), i32, i64, i32, i32p],
         "tfhe_sample_uniform": [vp, i32, u64, C.c_uint32, u64, vp, i64],
         "tfhe_sample_gaussian": [vp, i32, C.c_double, u64, u64, C.c_uint32, u64, vp, i64],
         "tfhe_ckks_encode": [vp, i32, u64, i32, vp, vp, i64],
@@ -156,7 +157,7 @@ EXPORTED_SYMBOLS = [
     "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_wait_for", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
     "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_pack_poly", "tfhe_unpack_poly", "tfhe_broadcast_poly", "tfhe_alloc_stats", "tfhe_alloc_trim", "tfhe_comm_id", "tfhe_comm_create", "tfhe_comm_destroy", "tfhe_gather", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
     "tfhe_mul", "tfhe_mad", "tfhe_dot", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
-    "tfhe_keyswitch", "tfhe_rotate", "tfhe_rotate_many", "tfhe_galois_key_prepare", "tfhe_matmul_diag", "tfhe_lincomb", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
+    "tfhe_keyswitch", "tfhe_rotate", "tfhe_rotate_many", "tfhe_galois_key_prepare", "tfhe_matmul_diag", "tfhe_lincomb", "tfhe_lincomb_many", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
     "tfhe_bfv_plan_set_variant", "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
     "tfhe_event_create", "tfhe_event_destroy", "tfhe_event_record", "tfhe_event_elapsed_ms",
 ]
@@ -312,6 +313,18 @@ class Context:
         S = (C.c_uint64 * len(flat))(*flat)
         A = (C.c_void_p * n)(*a_ptrs)
         check(lib().tfhe_lincomb(self.h, S, A, n, dst, count, limbs, _idx(idx)))
+
+    def lincomb_many(self, scalars, a_ptrs, dst_ptrs, count, limbs, idx=None):
+        """dst[o] = sum_k scalars[o][k] * a_k for every output o in one pass over the operands (tfhe_lincomb_many);
+        scalars: [n_out][n_terms][limbs] residues"""
+        n, no = len(a_ptrs), len(dst_ptrs)
+        flat = [int(x) for out in scalars for row in out for x in row]
+        if len(flat) != no * n * limbs:
+            raise AssertionError("tfhe_lincomb_many: one scalar per output, term and limb")
+        S = (C.c_uint64 * len(flat))(*flat)
+        A = (C.c_void_p * n)(*a_ptrs)
+        D = (C.c_void_p * no)(*dst_ptrs)
+        check(lib().tfhe_lincomb_many(self.h, S, A, n, D, no, count, limbs, _idx(idx)))
 
     def matmul_diag(self, key_limbs, level, special, evks, n_digits, gs, diags, ct, out, batch):
         ptrs = (C.c_void_p * max(1, len(evks)))(*[int(p) for p in evks])

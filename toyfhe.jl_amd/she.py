@@ -410,12 +410,29 @@ class CipherText:
         return CipherText(c0.params, out, Fraction(c0.scale) ** 2)
 
     @staticmethod
+    def _weight_residues(w: float, scale, moduli):
+        """FixedRational(w).x at the ciphertext's scale, ckks.jl:42 (ties to even), as residues"""
+        fr = Fraction(w) * Fraction(scale)
+        fl = fr.numerator // fr.denominator
+        rem = fr - fl
+        v = fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2) else 0)
+        return [int(v) % q for q in moduli]
+
+    @staticmethod
     def lincomb(cts, weights) -> "CipherText":
         """sum_k cts[k] * weights[k] for float weights (ct * float, ckksencoding.jl:99-102, and the + of rlwe_she.jl:231-245 per
         term): the scalar-weighted sums of a convolution over encrypted inputs (infer.jl:127-129) as ONE device pass per
         component (tfhe_lincomb); bit-identical to `sum(c.mul_plain(w) for c, w in zip(cts, weights))`."""
-        cts, weights = list(cts), [float(w) for w in weights]
-        if not cts or len(cts) != len(weights):
+        return CipherText.lincomb_many(cts, [weights])[0]
+
+    @staticmethod
+    def lincomb_many(cts, weight_rows) -> "list[CipherText]":
+        """[sum_k cts[k] * row[k] for row in weight_rows]: several weighted sums of the SAME ciphertexts -- the output channels of
+        a convolution layer (infer.jl:127-131: every channel weighs the same 49 encrypted inputs) -- with one pass over the
+        operands per component (tfhe_lincomb_many); each result bit-identical to `lincomb(cts, row)`."""
+        cts = list(cts)
+        rows = [[float(w) for w in row] for row in weight_rows]
+        if not cts or not rows or any(len(r) != len(cts) for r in rows):
             raise AssertionError("lincomb: as many ciphertexts as weights, at least one")
         c0 = cts[0]
         c0._need_scale()
@@ -423,21 +440,19 @@ class CipherText:
         for c in cts:
             if c.ring() != ring or len(c) != len(c0) or c.scale != c0.scale or c[0].count != n:
                 raise UsageError("lincomb: ciphertexts of one ring, length, batch and scale")
-        scal = []
-        for w in weights:                                 # FixedRational(w).x at the ciphertext's scale, ckks.jl:42 (ties to even)
-            fr = Fraction(w) * Fraction(c0.scale)
-            fl = fr.numerator // fr.denominator
-            rem = fr - fl
-            v = fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2) else 0)
-            scal.append([int(v) % q for q in ring.moduli])
+        scal = [[CipherText._weight_residues(w, c0.scale, ring.moduli) for w in row] for row in rows]
         primal = all(c.cs[0].primal is not None for c in cts)   # stay in the domain the operands are in
-        out = []
+        comps = [[] for _ in rows]
         for s_ in range(len(c0)):
             ab = [(c.cs[s_].coeffs_primal() if primal else c.cs[s_].coeffs_dual()) for c in cts]
-            o = DeviceBuffer(n * ring.L * ring.N)
-            ring.ctx.lincomb(scal, [x.ptr for x in ab], o.ptr, n, ring.L, ring.idx)
-            out.append(RingElement(ring, o, None, batch) if primal else RingElement(ring, None, o, batch))
-        return CipherText(c0.params, out, Fraction(c0.scale) ** 2)
+            outs = [DeviceBuffer(n * ring.L * ring.N) for _ in rows]
+            if len(rows) == 1:
+                ring.ctx.lincomb(scal[0], [x.ptr for x in ab], outs[0].ptr, n, ring.L, ring.idx)
+            else:
+                ring.ctx.lincomb_many(scal, [x.ptr for x in ab], [o.ptr for o in outs], n, ring.L, ring.idx)
+            for k, o in enumerate(outs):
+                comps[k].append(RingElement(ring, o, None, batch) if primal else RingElement(ring, None, o, batch))
+        return [CipherText(c0.params, out, Fraction(c0.scale) ** 2) for out in comps]
 
     def add_plain(self, x) -> "CipherText":
         """ct .+ float / ct .+ vector (:111-124): encoded at the ciphertext's scale and added to the first component."""
