@@ -172,7 +172,11 @@ def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=Fal
                       term = C[i][j].mul_plain(float(model["conv_w"][i, j, ch]))
                       acc = term if acc is None else acc + term
           conved.append(tf.modswitch(acc.add_plain(float(model["conv_b"][ch]))))
-      sq1 = [tf.modswitch(tf.keyswitch(ek, c * c)) for c in conved]
+      if fused:    # the four channels' squares, relinearisations and rescales as ONE batch of 4 K ciphertexts
+          big = tf.CipherText.concat(conved)
+          sq1 = tf.modswitch(tf.keyswitch(ek, big * big)).split([K] * 4)
+      else:
+          sq1 = [tf.modswitch(tf.keyswitch(ek, c * c)) for c in conved]
       fq1 = None
       for i in range(4):
           part = encrypted_matmul(gk, fq1_blocks[i], sq1[i], B, cache, fused)

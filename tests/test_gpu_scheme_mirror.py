@@ -402,6 +402,31 @@ def test_encrypted_mnist_with_hoisted_rotations():
     assert err2 < 1e-3 and agree2 == 1.0, (err2, agree2)
 
 
+def test_ciphertext_concat_and_split_are_the_batch_dimension():
+    """CipherText.concat / split: independent ciphertexts stacked in the batch dimension go through multiplication,
+    relinearisation and rescale together and come out word for word as they do one by one."""
+    N = 1 << 10
+    R = tf.NegacyclicRing(N, chain(2**40 + 1, 3, N) + [tf.nextprime(2**60 + 1, 1, 2 * N)])
+    params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    rng = tf.DeviceRng(31)
+    kp = tf.keygen(rng, params)
+    ek = tf.keygen_evalmult(rng, kp.priv)
+    nr = np.random.default_rng(3)
+    scale = 2**30
+    cts = [tf.encrypt(rng, kp, tf.ckks_encode(nr.normal(0, 1, shp).astype(complex), params.R_cipher(), scale), scale=scale)
+           for shp in ((N // 2,), (2, N // 2), (3, N // 2))]
+    big = tf.CipherText.concat(cts)
+    assert big[0].batch == 6
+    back = big.split([1, 2, 3])
+    for a, b in zip(back, cts):
+        assert all(np.array_equal(x.to_numpy().reshape(-1), y.to_numpy().reshape(-1)) for x, y in zip(a.cs, b.cs))
+    together = tf.modswitch(tf.keyswitch(ek, big * big)).split([1, 2, 3])
+    for a, c in zip(together, cts):
+        one = tf.modswitch(tf.keyswitch(ek, c * c))
+        assert a.scale == one.scale
+        assert all(np.array_equal(x.to_numpy().reshape(-1), y.to_numpy().reshape(-1)) for x, y in zip(a.cs, one.cs))
+
+
 def test_encrypted_mnist_fused_calls_give_the_same_logits_to_the_last_bit():
     """the pipeline with one tfhe_matmul_diag call per matrix product and one tfhe_lincomb per convolution channel and component
     (`--hoisted --fused`) against the hoisted path it replaces: identical ciphertext arithmetic, so the decrypted logits are equal

@@ -1523,37 +1523,53 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
             mk[ii] = evk[(((size_t)i * 2 + 0) * Lk + A.w.idx[j]) * n + k];
             md[ii] = evk[(((size_t)i * 2 + 1) * Lk + A.w.idx[j]) * n + k];
         }
-        for (u32 b = b_lo; b < b_hi; b++) {
-            u64* s1p = S + (((size_t)b * 2 + 0) * A.nw + j) * n + k;
-            u64* s2p = S + (((size_t)b * 2 + 1) * A.nw + j) * n + k;
-            acc128 s1{0, 0}, s2{0, 0};
-            u64 r1 = i0 ? *s1p : 0, r2 = i0 ? *s2p : 0;
-            int pend = 0;
+        // two ciphertexts per round: their digit words are requested together (one ciphertext at a time the loop was bound by the
+        // round trip of its `level` digit loads: 30 % of the multiplier rate, 1.5 TB/s)
+        for (u32 b0 = b_lo; b0 < b_hi; b0 += 2) {
+            const u32 bb[2] = {b0, b0 + 1 < b_hi ? b0 + 1 : b0};
+            u64 d[2][DCH], r1[2], r2[2];
 #pragma unroll
-            for (int ii = 0; ii < DCH; ii++) {
-                if (i0 + ii < A.level) {
-                    const u64 d = dig[(((size_t)b * A.level + i0 + ii) * A.nw + j) * n + k];
-                    acc_mac(s1, md[ii], d);
-                    acc_mac(s2, mk[ii], d);
-                    if (++pend == lazy) {
-                        r1 = addmod(r1, barrett_reduce128(s1.lo, s1.hi, L.br), L.q);
-                        r2 = addmod(r2, barrett_reduce128(s2.lo, s2.hi, L.br), L.q);
-                        s1 = acc128{0, 0}; s2 = acc128{0, 0}; pend = 0;
+            for (int h = 0; h < 2; h++) {
+                r1[h] = i0 ? S[(((size_t)bb[h] * 2 + 0) * A.nw + j) * n + k] : 0;
+                r2[h] = i0 ? S[(((size_t)bb[h] * 2 + 1) * A.nw + j) * n + k] : 0;
+#pragma unroll
+                for (int ii = 0; ii < DCH; ii++)
+                    if (i0 + ii < A.level) d[h][ii] = dig[(((size_t)bb[h] * A.level + i0 + ii) * A.nw + j) * n + k];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                acc128 s1{0, 0}, s2{0, 0};
+                int pend = 0;
+#pragma unroll
+                for (int ii = 0; ii < DCH; ii++) {
+                    if (i0 + ii < A.level) {
+                        acc_mac(s1, md[ii], d[h][ii]);
+                        acc_mac(s2, mk[ii], d[h][ii]);
+                        if (++pend == lazy) {
+                            r1[h] = addmod(r1[h], barrett_reduce128(s1.lo, s1.hi, L.br), L.q);
+                            r2[h] = addmod(r2[h], barrett_reduce128(s2.lo, s2.hi, L.br), L.q);
+                            s1 = acc128{0, 0}; s2 = acc128{0, 0}; pend = 0;
+                        }
+                    }
+                }
+                if (pend) {
+                    r1[h] = addmod(r1[h], barrett_reduce128(s1.lo, s1.hi, L.br), L.q);
+                    r2[h] = addmod(r2[h], barrett_reduce128(s2.lo, s2.hi, L.br), L.q);
+                }
+                if constexpr (EPI) {
+                    if (i0 + DCH >= A.level && j < (u32)A.level) {
+                        r1[h] = addmod(shoup_full(r1[h], A.pinv[j], L.q), K.epi_x[(((size_t)bb[h] * 2) * A.level + j) * n + k], L.q);
+                        r2[h] = shoup_full(r2[h], A.pinv[j], L.q);
                     }
                 }
             }
-            if (pend) {
-                r1 = addmod(r1, barrett_reduce128(s1.lo, s1.hi, L.br), L.q);
-                r2 = addmod(r2, barrett_reduce128(s2.lo, s2.hi, L.br), L.q);
-            }
-            if constexpr (EPI) {
-                if (i0 + DCH >= A.level && j < (u32)A.level) {
-                    r1 = addmod(shoup_full(r1, A.pinv[j], L.q), K.epi_x[(((size_t)b * 2) * A.level + j) * n + k], L.q);
-                    r2 = shoup_full(r2, A.pinv[j], L.q);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (h == 0 || bb[1] != bb[0]) {
+                    S[(((size_t)bb[h] * 2 + 0) * A.nw + j) * n + k] = r1[h];
+                    S[(((size_t)bb[h] * 2 + 1) * A.nw + j) * n + k] = r2[h];
                 }
             }
-            *s1p = r1;
-            *s2p = r2;
         }
     }
 }

@@ -249,6 +249,48 @@ class RingElement:
             return out
         return RingElement(self.ring, rep(self.primal), rep(self.dual), batch)
 
+    @staticmethod
+    def concat(els) -> "RingElement":
+        """the batches of several elements of one ring back to back (an unbatched element counts as a batch of one): independent
+        polynomials ride in the leading batch dimension of every device call.  The result holds the domain(s) ALL inputs hold."""
+        els = list(els)
+        ring = els[0].ring
+        assert all(e.ring == ring for e in els)
+        words = ring.L * ring.N
+        total = sum(e.count for e in els)
+        def cat(get):
+            if any(get(e) is None for e in els):
+                return None
+            out = DeviceBuffer(total * words)
+            off = 0
+            for e in els:
+                native.check(native.lib().tfhe_memcpy_d2d(ring.ctx.h, out.ptr + off * 8, get(e).ptr, e.count * words * 8))
+                off += e.count * words
+            return out
+        p, d = cat(lambda e: e.primal), cat(lambda e: e.dual)
+        if p is None and d is None:                      # mixed domains: bring everything to the coefficient domain
+            for e in els:
+                e.coeffs_primal()
+            p = cat(lambda e: e.primal)
+        return RingElement(ring, p, d, total)
+
+    def split(self, sizes) -> "list[RingElement]":
+        """inverse of concat: consecutive sub-batches of the given sizes (copies)"""
+        sizes = [int(x) for x in sizes]
+        assert sum(sizes) == self.count
+        words = self.ring.L * self.ring.N
+        out, off = [], 0
+        for sz in sizes:
+            def part(b):
+                if b is None:
+                    return None
+                o = DeviceBuffer(sz * words)
+                native.check(native.lib().tfhe_memcpy_d2d(self.ring.ctx.h, o.ptr, b.ptr + off * 8, sz * words * 8))
+                return o
+            out.append(RingElement(self.ring, part(self.primal), part(self.dual), sz))
+            off += sz * words
+        return out
+
     def _align(self, o):
         """(a, b) with equal batch: an unbatched operand is broadcast against a batched one"""
         self._check(o)

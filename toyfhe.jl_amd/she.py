@@ -454,6 +454,21 @@ class CipherText:
                 comps[k].append(RingElement(ring, o, None, batch) if primal else RingElement(ring, None, o, batch))
         return [CipherText(c0.params, out, Fraction(c0.scale) ** 2) for out in comps]
 
+    @staticmethod
+    def concat(cts) -> "CipherText":
+        """the batches of several ciphertexts (same parameters, length and scale) as one batched ciphertext: the independent
+        ciphertexts of one circuit layer share every device call that follows"""
+        cts = list(cts)
+        c0 = cts[0]
+        if any(len(c) != len(c0) or c.scale != c0.scale or c.ring() != c0.ring() for c in cts):
+            raise UsageError("concat: ciphertexts of one ring, length and scale")
+        return CipherText(c0.params, [RingElement.concat([c.cs[s_] for c in cts]) for s_ in range(len(c0))], c0.scale)
+
+    def split(self, sizes) -> "list[CipherText]":
+        """inverse of concat"""
+        parts = [x.split(sizes) for x in self.cs]
+        return [CipherText(self.params, [p[k] for p in parts], self.scale) for k in range(len(sizes))]
+
     def add_plain(self, x) -> "CipherText":
         """ct .+ float / ct .+ vector (:111-124): encoded at the ciphertext's scale and added to the first component."""
         self._need_scale()
