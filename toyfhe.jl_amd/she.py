@@ -411,12 +411,14 @@ class CipherText:
 
     @staticmethod
     def _weight_residues(w: float, scale, moduli):
-        """FixedRational(w).x at the ciphertext's scale, ckks.jl:42 (ties to even), as residues"""
-        fr = Fraction(w) * Fraction(scale)
-        fl = fr.numerator // fr.denominator
-        rem = fr - fl
-        v = fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2) else 0)
-        return [int(v) % q for q in moduli]
+        """FixedRational(w).x at the ciphertext's scale, ckks.jl:42 (ties to even), as residues.  Integer arithmetic on the
+        float's exact ratio (a layer has hundreds of weights: Fraction objects cost a millisecond per call)."""
+        n, d = float(w).as_integer_ratio()
+        sc = scale if isinstance(scale, Fraction) else Fraction(scale)
+        num, den = n * sc.numerator, d * sc.denominator
+        fl, rem = divmod(num, den)
+        v = fl + (1 if 2 * rem > den or (2 * rem == den and fl % 2) else 0)
+        return [v % q for q in moduli]
 
     @staticmethod
     def lincomb(cts, weights) -> "CipherText":
@@ -440,7 +442,8 @@ class CipherText:
         for c in cts:
             if c.ring() != ring or len(c) != len(c0) or c.scale != c0.scale or c[0].count != n:
                 raise UsageError("lincomb: ciphertexts of one ring, length, batch and scale")
-        scal = [[CipherText._weight_residues(w, c0.scale, ring.moduli) for w in row] for row in rows]
+        sc, mods = Fraction(c0.scale), list(ring.moduli)
+        scal = [[CipherText._weight_residues(w, sc, mods) for w in row] for row in rows]
         primal = all(c.cs[0].primal is not None for c in cts)   # stay in the domain the operands are in
         comps = [[] for _ in rows]
         for s_ in range(len(c0)):
