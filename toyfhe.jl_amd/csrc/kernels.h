@@ -1828,10 +1828,18 @@ template <int LOGB, int LOGT, int MASK>
 constexpr size_t fused_lds_bytes() {
     return ((size_t)lds_words<LOGB, LOGT>() + (MASK ? 2 * (size_t)fused_tw_words<LOGB, LOGT>() : 0)) * 8;
 }
-template <class A, int LOGB, int LOGT, bool PRELIFT = false>
+// SPMODE (special prime, N <= 2^LOGB): the ModulusRaised contraction inside the kernel instead of a tail kernel over T.
+//   1: the items are the SPECIAL limb of every ciphertext only (nitems = batch); their two coefficient rows t_P go to
+//      T [batch][2][N] (`out`)
+//   2: the items are the `level` ciphertext limbs (nitems = batch * level); the final store of each is
+//      out_s[b][j] = (INTT(S_j) - [t_P]) P^-1 + c_s[b][j]  (ArithFpMD) with t_P read from `tsp` (launch 1's rows) -- nothing
+//      intermediate is written, k_ks_rescale_add's 32 row moves per ciphertext become 2 written + 2 (x level, L2 hits) read.
+//   0: as before (no special prime: "+ c" in the store; special prime: sums to T for k_ks_rescale_add).
+template <class A, int LOGB, int LOGT, bool PRELIFT = false, int SPMODE = 0>
 __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ evd, const u64* __restrict__ ct,
                                                          u64* __restrict__ out, const ntt_limb_t* __restrict__ LT,
-                                                         ks_arg_t KA, int Lk, u32 nitems) {
+                                                         ks_arg_t KA, int Lk, u32 nitems, const u64* __restrict__ tsp = nullptr,
+                                                         const u64* __restrict__ zero_row = nullptr) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     constexpr int K1 = pass_k_fwd(LOGB, LOGT, 0), K2 = pass_k_fwd(LOGB, LOGT, K1), K3 = LOGB - K1 - K2;
     static_assert(K3 >= 1 && pass_k_fwd(LOGB, LOGT, K1 + K2) == K3, "three-pass forward schedule expected");
@@ -1850,9 +1858,10 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 #endif
     const u32 niter = xcd_limb_niter<TFHE_XCD_KS>(gridDim.x, nitems);
     for (u32 it = 0; it < niter; it++) {
-        const u32 item = xcd_limb_walk<TFHE_XCD_KS>(it, blockIdx.x, gridDim.x, nw, nitems);
+        const u32 nper = SPMODE == 1 ? 1u : (SPMODE == 2 ? level : nw);   // items per ciphertext
+        const u32 item = xcd_limb_walk<TFHE_XCD_KS>(it, blockIdx.x, gridDim.x, nper, nitems);
         if (item == ~0u) break;
-        const u32 b = item / nw, j = item % nw;
+        const u32 b = item / nper, j = SPMODE == 1 ? level : item % nper;
         const ntt_limb_t& Lj = LT[KA.w.idx[j]];
         typename A::ctx C = A::make(Lj);
         if constexpr (TFHE_TWL_KS != 0) fused_fill_tw<A, LOGB, LOGT, TFHE_TWL_KS>(lds, C);
@@ -1910,9 +1919,19 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 #pragma unroll
         for (int sidx = 0; sidx < 2; sidx++) {
             if (sidx) kst(6);
-            const u64* addend = (!KA.special && (u32)sidx < add_s) ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : nullptr;
-            u64* gdst = out + ((size_t)((b * 2 + sidx) * nw + j) << LOGB);
-            fused_inv_from_regs<A, LOGB, LOGT, false, (TFHE_TWL_KS & 2) != 0>(lds, acc[sidx], gdst, C, addend);  // N^-1 is in the key rows (k_evk_to_f64)
+            if constexpr (SPMODE == 2) {
+                C.md_pinv = (double)KA.pinv[j].w;   // P^-1 mod q_j < 2^52: exact
+                C.md_c = (u32)sidx < add_s ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : zero_row;
+                u64* gdst = out + ((size_t)((b * 2 + sidx) * level + j) << LOGB);
+                fused_inv_from_regs<A, LOGB, LOGT, false, (TFHE_TWL_KS & 2) != 0, ArithFpMD>(lds, acc[sidx], gdst, C, tsp + ((size_t)(b * 2 + sidx) << LOGB));
+            } else if constexpr (SPMODE == 1) {
+                u64* gdst = out + ((size_t)(b * 2 + sidx) << LOGB);
+                fused_inv_from_regs<A, LOGB, LOGT, false, (TFHE_TWL_KS & 2) != 0>(lds, acc[sidx], gdst, C, nullptr);
+            } else {
+                const u64* addend = (!KA.special && (u32)sidx < add_s) ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : nullptr;
+                u64* gdst = out + ((size_t)((b * 2 + sidx) * nw + j) << LOGB);
+                fused_inv_from_regs<A, LOGB, LOGT, false, (TFHE_TWL_KS & 2) != 0>(lds, acc[sidx], gdst, C, addend);  // N^-1 is in the key rows (k_evk_to_f64)
+            }
         }
         kst(7);
     }

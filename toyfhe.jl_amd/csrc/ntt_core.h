@@ -133,6 +133,7 @@ TFHE_HD u64 lift_digit(u64 x, const lift_t& f) {
 // ---------------------------------------------------------------------------------------------
 struct ArithInt {
     static constexpr bool prefetch_tw = false;
+    static constexpr bool moddown = false;
     typedef u64 elem;
     typedef tw_t tw;
     struct ctx {
@@ -183,6 +184,7 @@ constexpr bool fp_fwd_sweep_before(int nstages, int s) {
 }
 struct ArithFp {
     static constexpr bool prefetch_tw = true;
+    static constexpr bool moddown = false;   // ArithFpMD: the final store is the ModulusRaised contraction (inv_store)
     static constexpr bool fwd_sweep_before(int nstages, int s) { return fp_fwd_sweep_before(nstages, s); }
     typedef double elem;
     typedef ftw_t tw;
@@ -194,6 +196,9 @@ struct ArithFp {
         // LDS copies of the first 2^(K1+K2) entries of W / Winv (the first and middle passes' twiddles), set by the fused
         // kernels; read through ArithFpL
         const ftwd_t *Wl = nullptr, *Winvl = nullptr;
+        // ArithFpMD (k_ks_fused, SPMODE 2): P^-1 mod p and the addend row c (or a row of zeros) of the contraction
+        double md_pinv = 0.0;
+        const u64* md_c = nullptr;
     };
     static TFHE_HD ctx make(const ntt_limb_t& L) {
         return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.Wdb, L.Winvdb, L.ninv_d, L.w1inv_ninv_d, L.q};
@@ -276,6 +281,17 @@ struct ArithFpL : ArithFp {
 struct ArithFpD : ArithFp {
     static TFHE_HD u64 out_inv_scaled(elem v, const ctx& c) { return to_lds(fp_reduce(v, c.p, c.pinv)); }
     static TFHE_HD u64 out_inv_lazy(elem v, const ctx& c) { return to_lds(fp_reduce(v, c.p, c.pinv)); }
+};
+// ArithFp whose final store is the ModulusRaised contraction fused with the "+ c" of the key switch (modulusraising.jl:35-42,
+// crt.jl:215-220; k_ks_rescale_add):  out = (v - [t_P]) P^-1 + c  (mod p), with t_P the special limb's coefficient (canonical,
+// below 2^52: the unsigned representative, any residue of it mod p serves) arriving through the store phase's addend stream and c
+// through ctx::md_c.  Exact: |reduce(v) - reduce(t)| <= p + 2, the product is <= 0.88 p, plus c < p: 1.9 p into the canonicalisation.
+struct ArithFpMD : ArithFp {
+    static constexpr bool moddown = true;
+    static TFHE_HD u64 out_moddown(elem v, u64 tsp, u64 cw, const ctx& c) {
+        const double x = fp_reduce(v, c.p, c.pinv) - fp_reduce(fp_from_u64(tsp), c.p, c.pinv);
+        return fp_canon(fp_mulmod_c(x, ftw_t{c.md_pinv}, c.p, c.pinv) + fp_from_u64(cw), c.p, c.pinv);
+    }
 };
 // The fp64 policy for digit lifts whose SOURCE limb may be above 2^52 (the 60-bit q0 of the reference's CKKS rings next to
 // its 40-bit primes, infer.jl:98-107): such a residue does not fit a double, so that digit is centred and reduced in
@@ -603,14 +619,18 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
             // 32 serial round trips per inverse transform of the fused key switch, a fifth of that kernel's time; requested all
             // at once they left that kernel three registers short and three of them were spilled right behind their loads,
             // each with its own wait.  Four blocks keep two of them (E/2 words) in flight next to the results.
-            constexpr int NB = G::E >= 8 ? 4 : 1, BS = G::E / NB;
-            u64 add[2][BS];
+            // A::moddown (ArithFpMD): two streams -- `addend` is the special limb's row, ctx::md_c the ciphertext's -- in eight
+            // blocks (the same words in flight), and the store is the contraction instead of the sum.
+            constexpr bool MD = A::moddown;
+            constexpr int NB = G::E >= 8 ? (MD && G::E >= 16 ? 8 : 4) : 1, BS = G::E / NB;
+            u64 add[2][BS], add2[2][MD ? BS : 1];
             auto request = [&](int q) {
 #pragma unroll
                 for (int k = 0; k < BS; k++) {
                     const int e = q * BS + k, u = e / G::R, r = e % G::R;
                     if (USEL >= 0 && u != USEL) continue;
                     add[q & 1][k] = addend[pos[u] + ((u32)r << G::LO)];
+                    if constexpr (MD) add2[q & 1][k] = C.md_c[pos[u] + ((u32)r << G::LO)];
                 }
                 TFHE_SCHED_FENCE();
             };
@@ -620,13 +640,17 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
                 if (q + 1 < NB) request(q + 1);
                 u64 o[BS];
 #pragma unroll
-                for (int k = 0; k < BS; k++) o[k] = SCALE ? A::out_inv_scaled(v[q * BS + k], C) : A::out_inv_lazy(v[q * BS + k], C);
+                for (int k = 0; k < BS; k++) {
+                    if constexpr (MD) o[k] = A::out_moddown(v[q * BS + k], add[q & 1][k], add2[q & 1][k], C);
+                    else o[k] = SCALE ? A::out_inv_scaled(v[q * BS + k], C) : A::out_inv_lazy(v[q * BS + k], C);
+                }
                 TFHE_SCHED_FENCE();
 #pragma unroll
                 for (int k = 0; k < BS; k++) {
                     const int e = q * BS + k, u = e / G::R, r = e % G::R;
                     if (USEL >= 0 && u != USEL) continue;
-                    gdst[pos[u] + ((u32)r << G::LO)] = addmod(o[k], add[q & 1][k], C.q);
+                    if constexpr (MD) gdst[pos[u] + ((u32)r << G::LO)] = o[k];
+                    else gdst[pos[u] + ((u32)r << G::LO)] = addmod(o[k], add[q & 1][k], C.q);
                 }
                 TFHE_SCHED_FENCE();
             }

@@ -71,6 +71,9 @@ struct tfhe_ctx {
     std::map<int, conv_tab_t*> ksw_tabs;
     std::vector<void*> ksw_allocs;
     std::mutex ksw_mu;
+    // N zero words (the "+ c" stream of the fused contraction for the component that has no addend), made on first use
+    u64* zero_row = nullptr;
+    std::once_flag zero_once;
 };
 
 namespace {
@@ -635,6 +638,7 @@ int tfhe_ctx_destroy(tfhe_ctx* c) {
     for (auto* t : c->ksw_allocs) hipFree(t);
     if (c->limbs_dev) hipFree(c->limbs_dev);
     if (c->ws) hipFree(c->ws);
+    if (c->zero_row) hipFree(c->zero_row);
     for (auto& p : c->prof_pairs) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1243,6 +1247,47 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         // everything in one kernel: digit lift, forward transforms, key inner product and the two inverse transforms;
         // with the special prime the transformed sums go to S and the contraction kernel finishes (modulusraising.jl:42)
         const unsigned items = (unsigned)(batch * nw);
+        // Special prime: two launches -- the special limb of every ciphertext first (its coefficient rows t_P into S), then the
+        // ciphertext limbs with the ModulusRaised contraction and "+ c" in their final store (k_ks_fused SPMODE 1 / 2, ArithFpMD).
+        // No T, no tail kernel.  TFHE_KS_TAIL=1 keeps the one-launch form with k_ks_rescale_add (comparisons).
+        static const bool ks_tail = getenv("TFHE_KS_TAIL") && getenv("TFHE_KS_TAIL")[0] == '1';
+        if (special && !prelifted && !ks_tail) {
+            std::call_once(c->zero_once, [&] {
+                void* z = nullptr;
+                if (devalloc::malloc_retry(&z, (size_t)c->N * 8) == hipSuccess && hipMemset(z, 0, (size_t)c->N * 8) == hipSuccess) c->zero_row = (u64*)z;
+            });
+            if (!c->zero_row) return fail(TFHE_E_NOMEM, "allocating the zero row failed");
+            const u64 P = c->q[Lk - 1];
+            for (int j = 0; j < level; j++) A.pinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
+            const unsigned it1 = (unsigned)batch, it2 = (unsigned)(batch * level);
+            auto launch2 = [&](auto k1, auto k2, int LOGT, size_t lds, unsigned per_cu, bool& attr_set) -> int {
+                if (!attr_set) {
+                    int r2 = set_lds(k1, lds);
+                    if (!r2) r2 = set_lds(k2, lds);
+                    if (r2) return r2;
+                    attr_set = true;
+                }
+                prof_begin(c, (int64_t)items * (level + 2));
+                hipLaunchKernelGGL(k1, dim3(std::min(it1, per_cu * (unsigned)c->num_cus)), dim3(1u << LOGT), lds, c->stream, evd, ct, S, c->limbs_dev, A, Lk, it1,
+                                   (const u64*)nullptr, (const u64*)nullptr);
+                hipLaunchKernelGGL(k2, dim3(std::min(it2, per_cu * (unsigned)c->num_cus)), dim3(1u << LOGT), lds, c->stream, evd, ct, out, c->limbs_dev, A, Lk, it2,
+                                   (const u64*)S, (const u64*)c->zero_row);
+                prof_end(c);
+                return TFHE_OK;
+            };
+            if (c->logN == 14) {
+                constexpr int LOGT = logt_for(14);
+                static bool a14 = false;
+                rc = launch2(k_ks_fused<ArithFp, 14, LOGT, false, 1>, k_ks_fused<ArithFp, 14, LOGT, false, 2>, LOGT, fused_lds_bytes<14, LOGT, TFHE_TWL_KS>(), 1u, a14);
+            } else {
+                constexpr int LOGT = logt_for(13);
+                static bool a13 = false;
+                rc = launch2(k_ks_fused<ArithFp, 13, LOGT, false, 1>, k_ks_fused<ArithFp, 13, LOGT, false, 2>, LOGT, fused_lds_bytes<13, LOGT, TFHE_TWL_KS>(), 2u, a13);
+            }
+            if (rc) return rc;
+            HIP_TRY(hipGetLastError());
+            return TFHE_OK;
+        }
         if (c->logN == 14) {
             constexpr int LOGT = logt_for(14);
             const size_t lds = fused_lds_bytes<14, LOGT, TFHE_TWL_KS>();
@@ -1256,7 +1301,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
             }
             const unsigned grid = std::min(items, (unsigned)c->num_cus * TFHE_GRID_MULT_KS);
             prof_begin(c, (int64_t)items * (level + 2));  // limb transforms inside this launch: `level` forward + 2 inverse per item
-            hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, special ? S : out, c->limbs_dev, A, Lk, items);
+            hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, special ? S : out, c->limbs_dev, A, Lk, items, (const u64*)nullptr, (const u64*)nullptr);
             prof_end(c);
         } else {  // N = 2^13: 256 threads x 32 elements, 65 KiB of LDS; 478 registers per thread, so one workgroup per CU is resident
                   // (capped to two resident workgroups it measured 5 % slower)
@@ -1267,7 +1312,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
             if (!fattr13_set) { rc = set_lds(fk, lds); if (rc) return rc; fattr13_set = true; }
             const unsigned grid = std::min(items, 2u * (unsigned)c->num_cus);
             prof_begin(c, (int64_t)items * (level + 2));
-            hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, special ? S : out, c->limbs_dev, A, Lk, items);
+            hipLaunchKernelGGL(fk, dim3(grid), dim3(1 << LOGT), lds, c->stream, evd, ct, special ? S : out, c->limbs_dev, A, Lk, items, (const u64*)nullptr, (const u64*)nullptr);
             prof_end(c);
         }
         HIP_TRY(hipGetLastError());
