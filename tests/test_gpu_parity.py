@@ -319,6 +319,31 @@ def test_keyswitch_matches_oracle(N, bits, Lk, special):
         ctx.keyswitch(Lk, Lk + 1, special, devk.ptr, Lk, devk.ptr, 2, devk.ptr, 1)  # level outside the key ring
 
 
+@pytest.mark.parametrize("N,bits,Lk,level,batch", [(8192, 40, 6, 3, 300), (16384, 50, 5, 4, 270)])
+def test_keyswitch_special_prime_in_kernel_contraction_many_ciphertexts(N, bits, Lk, level, batch):
+    """The two-launch form of the fused key switch with a special prime (k_ks_fused SPMODE 1 / 2: the special limb's rows first,
+    then the ciphertext limbs with the ModulusRaised contraction in their final store, modulusraising.jl:35-49) on more
+    ciphertexts than there are workgroups (several items per workgroup in both launches), at a lower level of a longer key
+    (downswitch_keyelement, :43-49): the first and last ciphertexts against the oracle, every ciphertext against its own
+    single-ciphertext call."""
+    qs = H.chain(bits, Lk, N)
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(N + batch)
+    evk = H.uniform_evk(rng, qs, Lk, N)
+    devk = dev(evk)
+    ct = H.rand_residues(rng, qs[:level], (batch, 2), N)
+    dct, dout = dev(ct), tf.DeviceBuffer(batch * 2 * level * N)
+    ctx.keyswitch(Lk, level, True, devk.ptr, Lk, dct.ptr, 2, dout.ptr, batch)
+    got = dout.to_numpy((batch, 2, level, N))
+    pick = [0, 1, batch // 2, batch - 2, batch - 1]
+    want = ref.keyswitch(level, True, evk, ct[pick])
+    assert np.array_equal(got[pick], want)
+    one = tf.DeviceBuffer(2 * level * N)
+    for b in range(0, batch, 17):
+        ctx.keyswitch(Lk, level, True, devk.ptr, Lk, dev(ct[b:b + 1]).ptr, 2, one.ptr, 1)
+        assert np.array_equal(one.to_numpy((1, 2, level, N))[0], got[b]), b
+
+
 @pytest.mark.parametrize("special", [True, False])
 def test_keyswitch_mixed_modulus_sizes(special):
     """Key switch on a ring that mixes a 60-bit q0 with 40-bit primes (+ a 61-bit special prime): the digit lift stays on
