@@ -1065,6 +1065,10 @@ static int ks_digits_fwd(tfhe_ctx* c, const ks_arg_t& A, const u64* ct, u64* dig
 // forward transforms' loads (ntt_io_t::lift_unsigned: k_ntt_fwd_quad for the fp64-size limbs, k_ntt_fwd_top_lift + the u64 block
 // kernels for the others) and the factor P^-1 is left to k_md_acc; otherwise k_md_lift writes the scaled lifts to `LF` and plain
 // transforms follow.
+static bool md_lift_is_fused(const tfhe_ctx* c, int level) {
+    static const bool unfused = getenv("TFHE_MD_LIFT_UNFUSED") && getenv("TFHE_MD_LIFT_UNFUSED")[0] == '1';
+    return !unfused && c->logN == 16 && c->variant == 0 && level <= 32;
+}
 static int md_lift_fwd(tfhe_ctx* c, const ks_arg_t& A, const limb_sel_t& sl, const rescale_arg_t& ra, const u64* P, u64* LF, u64* U,
                        int64_t groups, bool* scaled) {
     const int level = A.level;
@@ -1073,8 +1077,7 @@ static int md_lift_fwd(tfhe_ctx* c, const ks_arg_t& A, const limb_sel_t& sl, con
     const u32 tmask = mask_of(level, [&](int j) { return c->limbs_host[sl.idx[j]].Wd != nullptr; });   // fp64-size target limbs
     const u32 tall = mask_all(level);
     const bool special_fp = c->limbs_host[A.w.idx[level]].Wd != nullptr;
-    static const bool unfused = getenv("TFHE_MD_LIFT_UNFUSED") && getenv("TFHE_MD_LIFT_UNFUSED")[0] == '1';
-    if (!unfused && c->logN == 16 && c->variant == 0 && level <= 32 && (rows << 2) <= 0x7fffffffll && (((uintptr_t)P | (uintptr_t)U) & 15u) == 0) {
+    if (md_lift_is_fused(c, level) && (rows << 2) <= 0x7fffffffll && (((uintptr_t)P | (uintptr_t)U) & 15u) == 0 && LF == nullptr) {
         ntt_io_t io = io_plain();
         io.mode = 1; io.level = 1; io.nw = (u32)level; io.polys = 1; io.lift_unsigned = 1;
         int rc;
@@ -1101,6 +1104,7 @@ static int md_lift_fwd(tfhe_ctx* c, const ks_arg_t& A, const limb_sel_t& sl, con
         *scaled = false;
         return TFHE_OK;
     }
+    if (!LF) return fail(TFHE_E_HIP, "md_lift_fwd: no buffer for the untransformed lifts");   // the caller sized the workspace for the fused form
     hipLaunchKernelGGL(k_md_lift, row_grid((unsigned)rows, (size_t)c->N), dim3(256), 0, c->stream, P, LF, c->limbs_dev, sl, ra, n);
     HIP_TRY(hipGetLastError());
     *scaled = true;
@@ -1560,13 +1564,24 @@ int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
     const bool eval_form = special && R > 0 && !md_coeff;
     // workspace per ciphertext: digits (level nw rows) + S / T (R 2 nw) + rotated ciphertexts (R 2 level) + the ciphertext's own transform (2 level)
     // (+ evaluation-domain form: the lifted special limbs before their transforms (R 2 level) and the special limbs themselves (R 2))
+    // (the untransformed lifts only where the lift is not fused into the transforms' loads)
+    const bool need_lf = eval_form && !(md_lift_is_fused(c, level) && (size_t)R * 2 * level * 4 * 512 <= 0x7fffffffull);
     const size_t per_ct = ((size_t)level * nw + (size_t)R * 2 * nw + (size_t)R * 2 * level + (size_t)2 * level +
-                           (eval_form ? (size_t)R * 2 * level + (size_t)R * 2 : 0)) * N * 8;
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)((8192ull << 20) / per_ct)}));
-    const size_t ntt_rows = (size_t)chunk * std::max<size_t>({(size_t)level * nw, (size_t)R * 2 * nw, (size_t)2 * level});
-    const size_t ntt_tmp = c->logN > 14 ? ntt_rows * N * 8 : 0;
+                           (eval_form ? (need_lf ? (size_t)R * 2 * level : 0) + (size_t)R * 2 : 0)) * N * 8;
+    // The keys of all R rotations are read once per chunk (2.8 GB at N = 2^16, 6 limbs + special prime, 63 rotations): a chunk as
+    // large as the memory allows (32 GiB of workspace unless TFHE_MD_WS_GIB says otherwise; halved while the allocation fails)
+    static const size_t ws_cap = [] { const char* e = getenv("TFHE_MD_WS_GIB"); const long g = e ? atol(e) : 0; return (size_t)(g > 0 ? g : 32) << 30; }();
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)(ws_cap / per_ct)}));
+    size_t ntt_tmp = 0;
     void* ws = nullptr;
-    int rc = ensure_ws(c, ntt_tmp + chunk * per_ct, &ws);
+    int rc;
+    for (;;) {
+        const size_t ntt_rows = (size_t)chunk * std::max<size_t>({(size_t)level * nw, (size_t)R * 2 * nw, (size_t)2 * level});
+        ntt_tmp = c->logN > 14 ? ntt_rows * N * 8 : 0;
+        rc = ensure_ws(c, ntt_tmp + chunk * per_ct, &ws);
+        if (rc != TFHE_E_NOMEM || chunk == 1) break;
+        chunk = (chunk + 1) / 2;
+    }
     if (rc) return rc;
     u64* dig = (u64*)((char*)ws + ntt_tmp);
     u64* S = dig + (size_t)chunk * level * nw * N;
@@ -1577,8 +1592,8 @@ int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
         const u64* cin = ct + (size_t)b0 * polys * level * N;
         if (eval_form) {
             u64* const U = ROT;                                  // [R][nb][2][level][N]
-            u64* const LF = X + (size_t)chunk * 2 * level * N;   // lifted special limbs, untransformed (same shape)
-            u64* const PB = LF + (size_t)chunk * R * 2 * level * N;   // [R][nb][2][N]
+            u64* const LF = need_lf ? X + (size_t)chunk * 2 * level * N : nullptr;   // lifted special limbs, untransformed (same shape)
+            u64* const PB = X + (size_t)chunk * 2 * level * N + (need_lf ? (size_t)chunk * R * 2 * level * N : 0);   // [R][nb][2][N]
             const u32 groups = (u32)((int64_t)R * nb * 2);
             rc = run_ntt(c, false, cin, X, nb * 2 * level, sl);
             if (rc) return rc;
