@@ -224,3 +224,14 @@ extern "C" double emul_centred_double(uint64_t r, uint64_t q) {
     memcpy(&d, &bits, 8);
     return d;
 }
+
+// ntt_core.h ArithFpMD::out_moddown: the ModulusRaised contraction + "+ c" in the fused key switch's final store, on one lazy
+// inverse-transform value v (an exact integer double, |v| < 7.9 p), the special limb's coefficient tsp and the addend word cw
+extern "C" uint64_t emul_out_moddown(double v, uint64_t tsp, uint64_t cw, uint64_t q, uint64_t pinv_modq) {
+    ArithFp::ctx C{};
+    C.p = (double)q;
+    C.pinv = 1.0 / (double)q;
+    C.q = q;
+    C.md_pinv = (double)pinv_modq;
+    return ArithFpMD::out_moddown(v, tsp, cw, C);
+}

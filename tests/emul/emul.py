@@ -110,3 +110,10 @@ def ckks_to_double(mag: int, neg: bool, smant, sexp):
 
 def centred_double(r: int, q: int) -> float:
     return lib().emul_centred_double(int(r), int(q))
+
+
+def out_moddown(v: float, tsp: int, cw: int, q: int, pinv_modq: int) -> int:
+    f = lib().emul_out_moddown
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    return int(f(float(v), int(tsp), int(cw), int(q), int(pinv_modq)))

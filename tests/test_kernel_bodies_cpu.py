@@ -274,3 +274,24 @@ def test_centred_double_hand_over(bits):
         want = r - q if r > q // 2 else r          # SignedMod-style centred representative (rlwe_she.jl:326-329)
         got = emul.centred_double(r, q)
         assert got == float(want) and float(int(got)) == got, (r, q, got, want)
+
+
+@pytest.mark.parametrize("bits,pbits", [(50, 50), (40, 50), (50, 40), (30, 45)])
+def test_fused_contraction_store_arithmetic(bits, pbits):
+    """ntt_core.h ArithFpMD::out_moddown (k_ks_fused SPMODE 2): (v - [t_P]) P^-1 + c mod q from a LAZY inverse-transform value
+    (any integer |v| < 7.9 q), the special limb's coefficient t_P in [0, P) and the addend c in [0, q) -- the canonical residue
+    of modulusraising.jl:35-42 / crt.jl:215-220 with the unsigned representative of t_P, at the edges of every range."""
+    N = 1 << 10
+    q = _chain(bits, 1, N)[0]
+    P = _chain(pbits, 2, N)[1]
+    pinv = pow(P % q, -1, q)
+    rng = np.random.default_rng(bits * 64 + pbits)
+    lim = int(7.9 * q)
+    vs = [0, 1, -1, q, -q, q // 2, q // 2 + 1, -(q // 2) - 1, lim - 1, -(lim - 1)] + [int(x) for x in rng.integers(-lim + 1, lim, size=300)]
+    ts = [0, 1, P - 1, P // 2, P // 2 + 1, q % P, (q - 1) % P] + [int(x) for x in rng.integers(0, P, size=40)]
+    cs = [0, 1, q - 1, q // 2] + [int(x) for x in rng.integers(0, q, size=8)]
+    for i, v in enumerate(vs):
+        for t in (ts if i < 12 else ts[i % len(ts):][:3]):
+            for c in (cs if i < 12 else cs[i % len(cs):][:2]):
+                want = ((v - t) * pinv + c) % q
+                assert emul.out_moddown(float(v), t, c, q, pinv) == want, (v, t, c)
