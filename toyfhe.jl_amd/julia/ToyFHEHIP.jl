@@ -239,6 +239,29 @@ function Base.broadcasted(::typeof(*), s::Union{Integer,CRTEncoded}, a::DevVec{T
 end
 Base.broadcasted(::typeof(*), a::DevVec{T}, s::Union{Integer,CRTEncoded}) where {T<:CRTEncoded} = Base.broadcasted(*, s, a)
 
+# [sum_k scalars[o][k] .* as[k] for o in outputs]: several scalar-weighted sums of the SAME operands in one pass over them
+# (tfhe_lincomb_many) -- the output channels of a convolution with plaintext scalar weights, infer.jl:127-131 (each channel is
+# `sum(C[i][j] * w[i,j,ch])`: per term one scalar_mul, pow2_cyc_rings.jl:177-185, and one +, :200-214).  One row of scalars per output.
+function lincomb_many(scalars::Vector{<:Vector}, as::Vector{<:DevVec{T}}) where {T<:CRTEncoded}
+    @assert !isempty(as) && !isempty(scalars)
+    xs = HipVector{T}[a.parent for a in as]; nterms = length(xs); nout = length(scalars)
+    for row in scalars
+        length(row) == nterms || throw(AssertionError("lincomb_many: one scalar per operand in every row"))
+    end
+    cnt = xs[1].count; limbs = xs[1].limbs; n = xs[1].n
+    for x in xs
+        samecount(x, xs[1])
+    end
+    flat = UInt64[convert(Integer, c) for row in scalars for s in row for c in convert(T, s).c]      # [nout][nterms][limbs]
+    dsts = HipVector{T}[HipVector{T}(limbs, n, cnt) for _ in 1:nout]; ctx = on(modring(T, n), (dsts...,), (xs...,))
+    ap = Ptr{UInt64}[x.ptr for x in xs]; dp = Ptr{UInt64}[d.ptr for d in dsts]
+    GC.@preserve xs dsts check(ccall((:tfhe_lincomb_many, lib), Cint,
+                (Ptr{Cvoid}, Ptr{UInt64}, Ptr{Ptr{UInt64}}, Cint, Ptr{Ptr{UInt64}}, Cint, Int64, Cint, Ptr{Int32}),
+                ctx.handle, flat, ap, nterms, dp, nout, cnt, limbs, C_NULL))
+    [OffsetArray(d, axes(as[1])...) for d in dsts]
+end
+lincomb(scalars::Vector, as::Vector{<:DevVec{T}}) where {T<:CRTEncoded} = lincomb_many([scalars], as)[1]
+
 # ---- K6/K7: modswitch / modswitch_drop / crtselect (crt.jl:185-236) --------------------------------------------------
 function ToyFHE.modswitch(re::RingElement{ℛ,T,S}) where {ℛ,T<:CRTEncoded,S<:HipVector{T}}
     src = coeffs_primal(re).parent; ℛ′ = ToyFHE.drop_last(ℛ); T′ = eltype(ℛ′)
