@@ -176,6 +176,7 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_block(con
             const ntt_limb_t& Li = LT[sel.idx[i]];
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
+            if (io.lift_unsigned) lf.qi = lf.half = ~0ull;
             lift_wide_consts<A>(lf);
             lift = &lf;
         }
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_lift(cons
         lift_t lf;
         lf.qi = LT[sel.idx[i]].q;
         lf.half = lf.qi >> 1;
+        if (io.lift_unsigned) lf.qi = lf.half = ~0ull;   // ntt_io_t::lift_unsigned
         for (u32 j = 0; j < io.nw; j++) {
             if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch lifts into this limb
             const u32 tid = fresh_tid();
@@ -486,6 +488,7 @@ __device__ __forceinline__ item_rows_t item_rows(u32 pl, const limb_sel_t& sel, 
         const ntt_limb_t& Li = LT[sel.idx[i]];
         const ntt_limb_t& Lj = LT[sel.idx[r.j]];
         lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
+        if (io.lift_unsigned) lf.qi = lf.half = ~0ull;
     } else if constexpr (IOMODE == 2) {
         const u32 g = pl / io.gsz, w = pl % io.gsz;
         r.srow = g * io.src_gstride + w;
@@ -614,6 +617,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
             const ntt_limb_t& Li = LT[sel.idx[i]];
             const ntt_limb_t& Lj = LT[sel.idx[j]];
             lf.qi = Li.q; lf.half = Li.q >> 1; lf.qj = Lj.q; lf.bj = Lj.br;
+            if (io.lift_unsigned) lf.qi = lf.half = ~0ull;
             lift_wide_consts<A>(lf);
         }
         if (io.limb_mask && !((io.limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
@@ -1125,6 +1129,7 @@ __global__ void k_ntt_fwd_generic(const u64* __restrict__ src, u64* __restrict__
         j = rem % io.nw;
         srow = (b * io.polys + io.polys - 1) * io.level + i;
         lf.qi = LT[sel.idx[i]].q; lf.half = lf.qi >> 1; lf.qj = LT[sel.idx[j]].q; lf.bj = LT[sel.idx[j]].br;
+        if (io.lift_unsigned) lf.qi = lf.half = ~0ull;
         lift = true;
     } else if (io.gsz) {
         const u32 g = pl / io.gsz, w = pl % io.gsz;
@@ -2312,7 +2317,7 @@ __global__ __launch_bounds__(256) void k_ks_rot_tail(const u64* __restrict__ T, 
 //   k_md_special_perm   P[grp]      = S'[grp][special] o pi_g            (XCD-cooperative gather, grp = (r * batch + b) * 2 + s)
 //   (inverse transform of P on the special limb)
 //   k_md_lift           U[grp][j]   = ([P[grp]] mod q_j) P^-1             (unsigned representative, crt.jl:215-220)
-//   (forward transforms of U; at N = 2^16 the lift is fused into their loads -- ntt_io_t::lift_unsigned -- and k_md_acc
+//   (forward transforms of U; where md_lift_is_fused the lift rides on their loads -- ntt_io_t::lift_unsigned -- and k_md_acc
 //   multiplies by P^-1 itself: USCALE)
 //   (V[grp][j] = S'[grp][j] P^-1 + X0[b][j] [s = 0] is what the key-sum kernels store for j < level: k_ks_inner<.., EPI>)
 //   k_md_acc            out[b][s][j][k] = diag_0[j][k] X[b][s][j][k] + sum_r diag_{r+1}[j][k] (V[grp][j][pi_r k] - U[grp][j][k])
@@ -2322,11 +2327,14 @@ __global__ __launch_bounds__(256) void k_ks_rot_tail(const u64* __restrict__ T, 
 __global__ __launch_bounds__(256) void k_md_special_perm(const u64* __restrict__ S, u64* __restrict__ P, rot_tail_arg_t G, u32 n, u32 nw,
                                                           u32 level, u32 batch, u32 ngroups) {
     const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-    for (u32 grp = xcd; grp < ngroups; grp += 8u) {
+    // small rows: an XCD's workgroups split into teams of n / 256 (a row each) instead of idling beyond the row
+    const u32 spt = n / blockDim.x >= nslot ? nslot : (n / blockDim.x ? n / blockDim.x : 1u), teams = nslot / spt, team = slot / spt, ts = slot % spt;
+    if (team >= teams) return;
+    for (u32 grp = team * 8u + xcd; grp < ngroups; grp += 8u * teams) {
         const u64 g = G.g[(grp >> 1) / batch];
         const u64* s = S + ((size_t)grp * nw + level) * n;
         u64* d = P + (size_t)grp * n;
-        for (u32 m = slot * blockDim.x + threadIdx.x; m < n; m += nslot * blockDim.x) d[m] = s[galois_ntt_pos(m, g, n)];
+        for (u32 m = ts * blockDim.x + threadIdx.x; m < n; m += spt * blockDim.x) d[m] = s[galois_ntt_pos(m, g, n)];
     }
 }
 // rows = ngroups * level, row = grp * level + j
@@ -2356,10 +2364,15 @@ __global__ __launch_bounds__(256) void k_md_acc(const u64* __restrict__ X, const
                                                  limb_sel_t sel, rot_tail_arg_t G, rescale_arg_t ra, u32 n, u32 nw, u32 nrot, u32 batch) {
     constexpr int KB = TFHE_MD_KB;
     const u32 level = (u32)sel.n;
-    const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3, stride = nslot * blockDim.x;
+    const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    // small rows: an XCD's workgroups split into teams of n / (256 KB) workgroups, a row pair each (at N = 2^13 one team per
+    // XCD had seven of its eight coefficient lanes clamped: half of the reference-size MNIST pass)
+    const u32 per = blockDim.x * KB, spt = n / per >= nslot ? nslot : (n / per ? n / per : 1u), teams = nslot / spt, team = slot / spt, ts = slot % spt;
+    if (team >= teams) return;
+    const u32 stride = spt * blockDim.x;
     const size_t dstride = (size_t)level * n, gstride = (size_t)batch * 2;   // diagonal stride; groups per rotation
     struct term_t { u64 v0[KB], v1[KB], u0[KB], u1[KB], d[KB]; };
-    for (u32 pr = xcd; pr < batch * level; pr += 8u) {
+    for (u32 pr = team * 8u + xcd; pr < batch * level; pr += 8u * teams) {
         const u32 j = pr % level, b = pr / level;
         const ntt_limb_t L = LT[sel.idx[j]];
         const tw_t pinv = ra.qlinv[j];
@@ -2368,7 +2381,7 @@ __global__ __launch_bounds__(256) void k_md_acc(const u64* __restrict__ X, const
         const u32 chunk = bits >= 62 ? 1u : (62 - bits >= 6 ? 64u : (1u << (62 - bits)));   // products summed between two reductions
         const size_t row0 = ((size_t)b * 2 * level + j) * n, row1 = row0 + (size_t)level * n;
         const u64* dj = diag + (size_t)j * n;
-        for (u32 kb = slot * blockDim.x + threadIdx.x; kb < n; kb += stride * KB) {
+        for (u32 kb = ts * blockDim.x + threadIdx.x; kb < n; kb += stride * KB) {
             u32 k[KB];
 #pragma unroll
             for (int i = 0; i < KB; i++) k[i] = kb + (u32)i * stride < n ? kb + (u32)i * stride : kb;   // (a clamped lane repeats kb; not stored)

@@ -335,7 +335,7 @@ struct ntt_io_t {
     const u64* addend;
     u32 limb_mask;    // != 0: only the items whose limb position (index into the selection) has its bit set -- rings that mix
                       // fp64-size and larger moduli are transformed by two launches, one per arithmetic policy
-    u32 lift_unsigned;  // mode 1, k_ntt_fwd_quad / k_ntt_fwd_top_lift only: the source rows are residues of a modulus OUTSIDE the
+    u32 lift_unsigned;  // mode 1: the source rows are residues of a modulus OUTSIDE the
                         // selection (the special prime) and are lifted as their unsigned representatives [x] mod q_j, the floor of
                         // modswitch (crt.jl:215-220), instead of centred digits; level = 1, polys = 1: source row = item / nw
 };

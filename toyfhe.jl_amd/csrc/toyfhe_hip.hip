@@ -1065,23 +1065,35 @@ static int ks_digits_fwd(tfhe_ctx* c, const ks_arg_t& A, const u64* ct, u64* dig
 // forward transforms' loads (ntt_io_t::lift_unsigned: k_ntt_fwd_quad for the fp64-size limbs, k_ntt_fwd_top_lift + the u64 block
 // kernels for the others) and the factor P^-1 is left to k_md_acc; otherwise k_md_lift writes the scaled lifts to `LF` and plain
 // transforms follow.
-static bool md_lift_is_fused(const tfhe_ctx* c, int level) {
+// Whether the unsigned lift can ride on the forward transforms' loads (ntt_io_t::lift_unsigned) for these target limbs and this
+// special prime: N = 2^15 / 2^16 through the pair / quad kernels (+ top-stage lift for the u64 limbs); N <= 2^14 through
+// run_ntt's digit-lift mode -- except when every target limb is fp64-size and the special prime is not (the uniform fp64 policy
+// reads its source as one double).
+static bool md_lift_is_fused(const tfhe_ctx* c, const ks_arg_t& A, const limb_sel_t& sl) {
     static const bool unfused = getenv("TFHE_MD_LIFT_UNFUSED") && getenv("TFHE_MD_LIFT_UNFUSED")[0] == '1';
-    return !unfused && c->logN == 16 && c->variant == 0 && level <= 32;
+    const int level = A.level;
+    if (unfused || level > 32 || c->logN > 16) return false;
+    if (c->logN >= 15) return c->variant == 0;
+    const bool special_fp = c->limbs_host[A.w.idx[level]].Wd != nullptr;
+    return special_fp || !sel_fp(c, sl, 0);
 }
 static int md_lift_fwd(tfhe_ctx* c, const ks_arg_t& A, const limb_sel_t& sl, const rescale_arg_t& ra, const u64* P, u64* LF, u64* U,
                        int64_t groups, bool* scaled) {
     const int level = A.level;
     const u32 n = (u32)c->N;
     const int64_t rows = groups * level;
-    const u32 tmask = mask_of(level, [&](int j) { return c->limbs_host[sl.idx[j]].Wd != nullptr; });   // fp64-size target limbs
-    const u32 tall = mask_all(level);
-    const bool special_fp = c->limbs_host[A.w.idx[level]].Wd != nullptr;
-    if (md_lift_is_fused(c, level) && (rows << 2) <= 0x7fffffffll && (((uintptr_t)P | (uintptr_t)U) & 15u) == 0 && LF == nullptr) {
+    if (LF == nullptr) {   // the caller sized the workspace for the fused form (md_lift_is_fused)
         ntt_io_t io = io_plain();
         io.mode = 1; io.level = 1; io.nw = (u32)level; io.polys = 1; io.lift_unsigned = 1;
+        *scaled = false;
+        if (c->logN <= 14) return run_ntt(c, false, P, U, rows, sl, &io);
+        const int x = c->logN - 14;
+        const u32 tmask = mask_of(level, [&](int j) { return c->limbs_host[sl.idx[j]].Wd != nullptr; });   // fp64-size target limbs
+        const u32 tall = mask_all(level);
+        const bool special_fp = c->limbs_host[A.w.idx[level]].Wd != nullptr;
+        if ((rows << x) > 0x7fffffffll || (((uintptr_t)P | (uintptr_t)U) & 15u) != 0) return fail(TFHE_E_BADARG, "md_lift_fwd: row count / alignment");
         int rc;
-        if (tmask) {   // the fp64-size limbs: one kernel per row pair (ArithFpWide reads a source above 2^52 in two halves)
+        if (tmask) {   // the fp64-size limbs: one kernel per row (pair) (ArithFpWide reads a source above 2^52 in two halves)
             ntt_io_t a = io;
             a.limb_mask = tmask == tall ? 0u : tmask;
             rc = run_ntt_large(c, false, P, U, rows, sl, a, &a, true, !special_fp);
@@ -1093,18 +1105,17 @@ static int md_lift_fwd(tfhe_ctx* c, const ks_arg_t& A, const limb_sel_t& sl, con
             if (rc) return rc;
             ntt_io_t w = io;
             w.limb_mask = tmask ? (tall & ~tmask) : 0u;
-            const dim3 tg((unsigned)((((c->N >> 2) + 255) / 256) * rows));
-            hipLaunchKernelGGL(k_ntt_fwd_top_lift<2>, tg, dim3(256), 0, c->stream, P, (u64*)tmp, c->limbs_dev, sl, c->logN, w);
+            const dim3 tg((unsigned)((((c->N >> x) + 255) / 256) * rows));
+            if (x == 1) hipLaunchKernelGGL(k_ntt_fwd_top_lift<1>, tg, dim3(256), 0, c->stream, P, (u64*)tmp, c->limbs_dev, sl, c->logN, w);
+            else hipLaunchKernelGGL(k_ntt_fwd_top_lift<2>, tg, dim3(256), 0, c->stream, P, (u64*)tmp, c->limbs_dev, sl, c->logN, w);
             HIP_TRY(hipGetLastError());
             ntt_io_t ib = io_plain();
             ib.limb_mask = w.limb_mask;
-            rc = launch_block_fwd<ArithInt, 14>(c, (const u64*)tmp, U, rows, sl, 2, ib);
+            rc = launch_block_fwd<ArithInt, 14>(c, (const u64*)tmp, U, rows, sl, x, ib);
             if (rc) return rc;
         }
-        *scaled = false;
         return TFHE_OK;
     }
-    if (!LF) return fail(TFHE_E_HIP, "md_lift_fwd: no buffer for the untransformed lifts");   // the caller sized the workspace for the fused form
     hipLaunchKernelGGL(k_md_lift, row_grid((unsigned)rows, (size_t)c->N), dim3(256), 0, c->stream, P, LF, c->limbs_dev, sl, ra, n);
     HIP_TRY(hipGetLastError());
     *scaled = true;
@@ -1565,7 +1576,7 @@ int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
     // workspace per ciphertext: digits (level nw rows) + S / T (R 2 nw) + rotated ciphertexts (R 2 level) + the ciphertext's own transform (2 level)
     // (+ evaluation-domain form: the lifted special limbs before their transforms (R 2 level) and the special limbs themselves (R 2))
     // (the untransformed lifts only where the lift is not fused into the transforms' loads)
-    const bool need_lf = eval_form && !(md_lift_is_fused(c, level) && (size_t)R * 2 * level * 4 * 512 <= 0x7fffffffull);
+    const bool need_lf = eval_form && !(md_lift_is_fused(c, A, sl) && (size_t)R * 2 * level * 4 * 512 <= 0x7fffffffull);
     const size_t per_ct = ((size_t)level * nw + (size_t)R * 2 * nw + (size_t)R * 2 * level + (size_t)2 * level +
                            (eval_form ? (need_lf ? (size_t)R * 2 * level : 0) + (size_t)R * 2 : 0)) * N * 8;
     // The keys of all R rotations are read once per chunk (2.8 GB at N = 2^16, 6 limbs + special prime, 63 rotations): a chunk as
