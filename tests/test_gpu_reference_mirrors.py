@@ -328,3 +328,38 @@ def test_lincomb_equals_the_sum_of_scalar_products():
         tf.CipherText.lincomb_many(cts, [ws, ws[:-1]])
     with pytest.raises(AssertionError):
         tf.CipherText.lincomb(cts, ws[:-1])
+
+
+def test_more_than_one_device_pass_of_terms_and_rotations():
+    """A device pass takes 64 operands / rotations (TFHE_DOT_MAX): longer weighted sums and diagonal products are split on the
+    host into partial sums (she.DOT_MAX) -- same words as the term-by-term / rotate_many + dot_plain compositions."""
+    N = 256                                                                    # 127 distinct rotation steps
+    qs = chain(2**40 + 1, 3, N)
+    params = tf.ModulusRaised(tf.CKKSParams(tf.NegacyclicRing(N, qs), 0, 3.2))
+    rng = tf.DeviceRng(4100)
+    kp = tf.keygen(rng, params)
+    R = params.R_cipher()
+    scale = 2**30
+    nrng = np.random.default_rng(41)
+    cts = [tf.encrypt(rng, kp, tf.ckks_encode(nrng.normal(0, 1, (N // 2,)).astype(complex), R, scale), scale=scale) for _ in range(70)]
+    ws = list(nrng.normal(0, 0.3, 70))
+    want = None
+    for c, w in zip(cts, ws):
+        t = c.mul_plain(float(w))
+        want = t if want is None else want + t
+    got = tf.CipherText.lincomb(cts, ws)
+    for a, b in zip(got.cs, want.cs):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
+    n_rot = 67
+    c = cts[0]
+    gks = [tf.keygen_galois(rng, kp.priv, steps=int(k)) for k in range(1, n_rot + 1)]
+    singles = [tf.ckks_encode(nrng.normal(0, 1, (N // 2,)).astype(complex), R, scale) for _ in range(n_rot + 1)]
+    rots = list(tf.rotate_many(gks[:64], c)) + list(tf.rotate_many(gks[64:], c))
+    want = tf.CipherText.dot_plain([c] + rots[:63], singles[:64]) + tf.CipherText.dot_plain(rots[63:], singles[64:])
+    got = tf.matmul_diag(gks, singles, c)
+    for a, b in zip(got.cs, want.cs):
+        assert np.array_equal(a.to_numpy("dual"), b.to_numpy("dual"))
+    stacked = tf.RingElement.concat(singles)
+    got2 = tf.matmul_diag(gks, stacked, c)
+    for a, b in zip(got2.cs, got.cs):
+        assert np.array_equal(a.to_numpy("dual"), b.to_numpy("dual"))

@@ -77,6 +77,41 @@ def test_bfv_crt():
         c * tf.CipherText(other, c.cs)
 
 
+def test_bfv_enc_mul_any_component_counts():
+    """enc_mul as rlwe_she.jl:247-262 writes it -- any numbers of components: (c*c)*c without relinearisation (3 x 2 -> 4
+    components), bit for bit against the oracle's switch -> convolution over ℛbig -> multround/switch, and decrypted with
+    s, s^2, s^3 (rlwe_she.jl:199-217).  Superset and disjoint extension bases; a batch as well."""
+    n = 1024
+    ch = chain(2**50 + 1, 9, n)
+    for big_limbs in (ch[:7], ch[2:9]):
+        R, Rbig = tf.NegacyclicRing(n, ch[:2]), tf.NegacyclicRing(n, big_limbs)
+        params = tf.BFVParams(R, Rbig, 17, 0, 3.2)
+        rng = np.random.default_rng(11)
+        kp = tf.keygen(rng, params)
+        c = tf.encrypt(rng, kp, [3] + [0] * (n - 1))
+        d = tf.encrypt(rng, kp, [[2] + [0] * (n - 1), [5, 1] + [0] * (n - 2)])          # a batch of two
+        y = c * c
+        z = y * c                                                                        # 3 x 2
+        assert len(z) == 4 and tf.decrypt(kp, z)[0] == 27 % 17
+        w = c * y                                                                        # 2 x 3
+        assert len(w) == 4
+        rs, rb = ref_cpu.RefCtx(n, ch[:2]), ref_cpu.RefCtx(n, big_limbs)
+
+        def want(a, b):
+            ea = ref_cpu.switch(rs, rb, np.stack([x.to_numpy("primal") for x in a.cs]).reshape(-1, 2, n)).reshape(1, len(a), len(big_limbs), n)
+            eb = ref_cpu.switch(rs, rb, np.stack([x.to_numpy("primal") for x in b.cs]).reshape(-1, 2, n)).reshape(1, len(b), len(big_limbs), n)
+            return ref_cpu.contract(rb, rs, 17, rb.enc_mul(ea, eb)[0])
+
+        for got, exp in ((z, want(y, c)), (w, want(c, y))):
+            assert np.array_equal(np.stack([x.to_numpy("primal") for x in got.cs]).reshape(exp.shape), exp)
+        assert all(np.array_equal(a.to_numpy("primal"), b.to_numpy("primal")) for a, b in zip(z.cs, w.cs))   # commutes
+        zz = (d * d) * d                                                                 # batched, 3 x 2
+        dec = tf.decrypt(kp, zz)
+        assert dec[0][0] == 8 and dec[1][:4] == [125 % 17, 75 % 17, 15, 1]                # (5 + x)^3 = 125 + 75 x + 15 x^2 + x^3
+        q4 = y * y                                                                       # 3 x 3 -> 5 components
+        assert len(q4) == 5 and tf.decrypt(kp, q4)[0] == 81 % 17
+
+
 def test_bfv_keyswitch_window():
     """test/bfv_keyswitch.jl:5-27 with the reference's default digit window (relin_window = 1, rlwe_she.jl:271):
     single-modulus ciphertext ring, base-2 evaluation key with one component per bit of q."""

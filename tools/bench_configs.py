@@ -18,6 +18,7 @@ import toyfhe_jl_amd as tf
 from oracle import ref_cpu            # checker only
 
 HBM_PEAK_GBS = 8000.0
+PROFILE = os.environ.get("TFHE_CFG_PROFILE", "0") not in ("", "0")
 RECORDS = []                          # one dict per case (bench.py puts them into its JSON line as `other_configs`)
 
 
@@ -31,7 +32,13 @@ def chain(start, n, N):
 
 def timed(ctx, f, reps=8):
     """best of three rounds after >= 0.1 s of warm-up (the oracle check before each case idles the GPU for seconds and the
-    clocks take tens of milliseconds to come back)"""
+    clocks take tens of milliseconds to come back).  TFHE_CFG_PROFILE=1 (tools/pmc_configs.sh, counter passes): three warm calls
+    and five counted ones -- the folding script drops the first quarter of every kernel's dispatches."""
+    if PROFILE:
+        for _ in range(8):
+            f()
+        ctx.sync()
+        return 1.0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.1:
         f()

@@ -6,7 +6,9 @@
 // (the encrypted-MNIST circuit was host-bound for that reason).  This allocator recycles blocks by exact size:
 //
 //   tfhe_free(p)  : no synchronisation.  An event is recorded on the stream of every live context (all product work runs
-//                   on context streams); the block is parked until those events have completed.
+//                   on context streams); the block is parked until those events have completed.  A cache that has grown past
+//                   its bound is trimmed by the NEXT tfhe_malloc (want_trim), never here.  The one waiting path left is the
+//                   fallback when an event cannot be created or recorded (a stream the caller destroyed): a plain hipFree.
 //   tfhe_malloc(n): polls the parked blocks in FIFO order (events complete in order), then hands out a ready block of the
 //                   same size, or falls back to hipMalloc; on out-of-memory the cache is drained and the call retried.
 //
@@ -52,6 +54,7 @@ struct dev_state_t {  // the cache of one device
     std::deque<parked_t> parked;                                 // freed, waiting for their events
     std::vector<hipEvent_t> ev_pool;                             // events of this device
     size_t cached_bytes = 0, max_cached = 0;
+    bool want_trim = false;                                      // the cache passed its bound in release(): trimmed by the next alloc()
 };
 
 struct state_t {
@@ -116,7 +119,7 @@ inline void poll_locked(dev_state_t& d) {
             if (hipEventQuery(ev) != hipSuccess) { done = false; break; }
         if (!done) { (void)hipGetLastError(); break; }
         for (hipEvent_t ev : b.evs) d.ev_pool.push_back(ev);
-        d.ready[b.bytes].push_back(b.p);
+        if (b.p) d.ready[b.bytes].push_back(b.p);                // (p == nullptr: the events of a block alloc_ws took while parked)
         d.parked.pop_front();
     }
 }
@@ -130,7 +133,7 @@ inline void trim_locked(state_t& s) {
     d.ready.clear();
     for (auto& b : d.parked) {
         for (hipEvent_t ev : b.evs) d.ev_pool.push_back(ev);
-        (void)hipFree(b.p);
+        if (b.p) (void)hipFree(b.p);
     }
     d.parked.clear();
     s.cached_bytes -= d.cached_bytes;
@@ -158,6 +161,10 @@ inline hipError_t alloc(size_t bytes, void** out) {
     if (!s.enabled) return hipMalloc(out, bytes);
     const int dev = current_device();
     dev_state_t& d = dev_locked(s, dev);
+    if (d.want_trim) {                                           // deferred from release(), which must never wait (GC finalizer threads)
+        d.want_trim = false;
+        if (d.cached_bytes > d.max_cached) trim_locked(s);
+    }
     poll_locked(d);
     auto it = d.ready.find(bytes);
     if (it != d.ready.end() && !it->second.empty()) {
@@ -179,6 +186,55 @@ inline hipError_t alloc(size_t bytes, void** out) {
     s.live[*out] = live_t{bytes, dev};
     s.live_bytes += bytes;
     return hipSuccess;
+}
+
+// A large per-call workspace for work on ONE stream (ensure_ws(pooled)): any cached block of `bytes` .. 2 x `bytes` serves --
+// a ready one as it is, a PARKED one after `stream` has been made to wait for its release events (the device orders the
+// reuse; the host does not wait), so successive calls of similar shape share one block even while the host runs ahead of
+// the GPU.  *got = the block's real size.
+inline hipError_t alloc_ws(size_t bytes, hipStream_t stream, void** out, size_t* got) {
+    {
+        state_t& s = S();
+        std::lock_guard<std::mutex> g(s.mu);
+        lazy_init(s);
+        if (s.enabled) {
+            const int dev = current_device();
+            dev_state_t& d = dev_locked(s, dev);
+            poll_locked(d);
+            size_t best = 0;
+            for (auto& kv : d.ready)
+                if (kv.first >= bytes && kv.first <= 2 * bytes && !kv.second.empty() && (best == 0 || kv.first < best)) best = kv.first;
+            if (best) {
+                *out = d.ready[best].back();
+                d.ready[best].pop_back();
+            } else {
+                for (auto it = d.parked.begin(); it != d.parked.end(); ++it) {
+                    if (it->bytes < bytes || it->bytes > 2 * bytes) continue;
+                    bool ok = true;
+                    for (hipEvent_t ev : it->evs)
+                        if (hipStreamWaitEvent(stream, ev, 0) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+                    if (!ok) continue;
+                    // the events stay out of the pool until they have completed: recycle them through a zero-byte parked entry
+                    best = it->bytes;
+                    *out = it->p;
+                    parked_t rest{nullptr, 0, std::move(it->evs)};
+                    *it = std::move(rest);
+                    break;
+                }
+            }
+            if (best) {
+                d.cached_bytes -= best;
+                s.cached_bytes -= best;
+                s.n_reuse++;
+                s.live[*out] = live_t{best, dev};
+                s.live_bytes += best;
+                *got = best;
+                return hipSuccess;
+            }
+        }
+    }
+    *got = bytes;
+    return alloc(bytes, out);
 }
 
 inline hipError_t release(void* p) {
@@ -217,7 +273,7 @@ inline hipError_t release(void* p) {
         d.parked.push_back(std::move(b));
         d.cached_bytes += bytes;
         s.cached_bytes += bytes;
-        if (d.cached_bytes > d.max_cached) trim_locked(s);
+        if (d.cached_bytes > d.max_cached) d.want_trim = true;   // no device synchronisation here: the next alloc() trims
     } else {
         for (hipEvent_t e2 : b.evs) d.ev_pool.push_back(e2);
         rc = hipFree(p);                                         // synchronising free

@@ -2002,7 +2002,13 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                     for (int r = 0; r < PE; r++) {
                         const u32 k = tp + ((u32)(h * PE + r) << LOGT);
 #pragma unroll
-                        for (int m = 0; m < (1 << X); m++) q[m][r] = grow[k + ((u32)m << LOGB)];
+                        for (int m = 0; m < (1 << X); m++) {
+#ifdef TFHE_ABL_NOROWS  // design aid: operands from arithmetic (wrong results, no row traffic)
+                            q[m][r] = (u64)(k * 131u + (u32)m * 7919u) + (u64)(size_t)grow; pin_vgpr(q[m][r]);
+#else
+                            q[m][r] = grow[k + ((u32)m << LOGB)];
+#endif
+                        }
                     }
                     TFHE_SCHED_FENCE();
 #pragma unroll

@@ -62,6 +62,7 @@ struct tfhe_ctx {
     // workspace (grown on demand, reused)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    bool ws_pooled = false;   // the block came from the recycling allocator (large per-call workspaces, ws_giveback)
     // profiling
     bool prof = false;
     std::vector<prof_pair> prof_pairs;
@@ -72,26 +73,55 @@ struct tfhe_ctx {
     std::vector<void*> ksw_allocs;
     std::mutex ksw_mu;
     // N zero words (the "+ c" stream of the fused contraction for the component that has no addend), made on first use
+    // (under zero_mu; a failed attempt is retried by the next call)
     u64* zero_row = nullptr;
-    std::once_flag zero_once;
+    std::mutex zero_mu;
 };
 
 namespace {
 
-int ensure_ws(tfhe_ctx* c, size_t bytes, void** out) {
+// pooled: the block is taken from (and, by ws_giveback, returned to) the recycling allocator instead of being owned by the
+// context for its lifetime -- for the large per-call workspaces (tfhe_matmul_diag: tens of GiB).  A parked block is reused by
+// the next call of the same shape without a synchronisation, counts against the allocator's cache bound, and is given back to
+// the driver by tfhe_alloc_trim and by every out-of-memory retry of the library (devalloc::malloc_retry).
+int ensure_ws(tfhe_ctx* c, size_t bytes, void** out, bool pooled = false) {
     if (bytes > c->ws_bytes) {
         if (c->ws) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            HIP_TRY(hipFree(c->ws));
+            if (c->ws_pooled) {
+                HIP_TRY(devalloc::release(c->ws));               // parked behind events on every context stream: no wait
+            } else {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                HIP_TRY(hipFree(c->ws));
+            }
             c->ws = nullptr;
             c->ws_bytes = 0;
         }
-        hipError_t e = devalloc::malloc_retry(&c->ws, bytes);
-        if (e != hipSuccess) return fail(TFHE_E_NOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        c->ws_bytes = bytes;
+        size_t got = bytes;
+        hipError_t e = pooled ? devalloc::alloc_ws(bytes, c->stream, &c->ws, &got) : devalloc::malloc_retry(&c->ws, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); c->ws = nullptr; return fail(TFHE_E_NOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        c->ws_bytes = got;
+        c->ws_pooled = pooled;
     }
     *out = c->ws;
     return TFHE_OK;
+}
+// a pooled workspace goes back to the allocator when the call that sized it returns
+void ws_giveback(tfhe_ctx* c) {
+    if (c->ws && c->ws_pooled) {
+        (void)devalloc::release(c->ws);
+        c->ws = nullptr;
+        c->ws_bytes = 0;
+        c->ws_pooled = false;
+    }
+}
+struct ws_guard_t {
+    tfhe_ctx* c;
+    ~ws_guard_t() { ws_giveback(c); }
+};
+// workspaces above this size are per-call (pooled); TFHE_WS_KEEP_GIB overrides
+size_t ws_keep_bytes() {
+    static const size_t keep = [] { const char* e = getenv("TFHE_WS_KEEP_GIB"); const long g = e ? atol(e) : 0; return (size_t)(g > 0 ? g : 4) << 30; }();
+    return keep;
 }
 
 int make_sel(const tfhe_ctx* c, int limbs, const int32_t* idx, limb_sel_t* sel) {
@@ -637,7 +667,7 @@ int tfhe_ctx_destroy(tfhe_ctx* c) {
     for (auto* t : c->tabs) hipFree(t);
     for (auto* t : c->ksw_allocs) hipFree(t);
     if (c->limbs_dev) hipFree(c->limbs_dev);
-    if (c->ws) hipFree(c->ws);
+    if (c->ws) { if (c->ws_pooled) (void)devalloc::release(c->ws); else hipFree(c->ws); }
     if (c->zero_row) hipFree(c->zero_row);
     for (auto& p : c->prof_pairs) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -812,6 +842,7 @@ int tfhe_lincomb(tfhe_ctx* c, const uint64_t* scalars, const uint64_t* const* a,
                  const int32_t* idx) {
     if (!c || !scalars || !a || !dst) return fail(TFHE_E_BADARG, "null argument");
     if (n_terms < 1) return fail(TFHE_E_BADARG, "tfhe_lincomb needs at least one term");
+    if (n_terms > TFHE_DOT_MAX) return fail(TFHE_E_UNSUPPORTED, "tfhe_lincomb takes at most %d terms per call", TFHE_DOT_MAX);
     limb_sel_t sel;
     int rc = make_sel(c, limbs, idx, &sel);
     if (rc) return rc;
@@ -829,14 +860,12 @@ int tfhe_lincomb(tfhe_ctx* c, const uint64_t* scalars, const uint64_t* const* a,
     void* dsc = nullptr;
     hipError_t e = devalloc::alloc(sc.size() * 8, &dsc);
     if (e != hipSuccess) return fail(TFHE_E_NOMEM, "hipMalloc(%zu): %s", sc.size() * 8, hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(dsc, sc.data(), sc.size() * 8, hipMemcpyHostToDevice, c->stream));   // pageable source: staged before the call returns
-    u64* tmp = nullptr;  // more than 64 terms: partial sums are added up by a second pass of the same kernel with unit scalars
-    const int nchunks = (n_terms + TFHE_DOT_MAX - 1) / TFHE_DOT_MAX;
-    if (nchunks > 1) {
+    e = hipMemcpyAsync(dsc, sc.data(), sc.size() * 8, hipMemcpyHostToDevice, c->stream);   // pageable source: staged before the call returns
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
         devalloc::release(dsc);
-        return fail(TFHE_E_UNSUPPORTED, "tfhe_lincomb takes at most %d terms per call", TFHE_DOT_MAX);
+        return fail(TFHE_E_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
     }
-    (void)tmp;
     dot_arg_t D;
     D.n = n_terms;
     for (int k = 0; k < n_terms; k++) { D.a[k] = a[k]; D.b[k] = nullptr; }
@@ -1267,11 +1296,17 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         // No T, no tail kernel.  TFHE_KS_TAIL=1 keeps the one-launch form with k_ks_rescale_add (comparisons).
         static const bool ks_tail = getenv("TFHE_KS_TAIL") && getenv("TFHE_KS_TAIL")[0] == '1';
         if (special && !prelifted && !ks_tail) {
-            std::call_once(c->zero_once, [&] {
-                void* z = nullptr;
-                if (devalloc::malloc_retry(&z, (size_t)c->N * 8) == hipSuccess && hipMemset(z, 0, (size_t)c->N * 8) == hipSuccess) c->zero_row = (u64*)z;
-            });
-            if (!c->zero_row) return fail(TFHE_E_NOMEM, "allocating the zero row failed");
+            {
+                std::lock_guard<std::mutex> zg(c->zero_mu);         // a failed attempt (transient out-of-memory) is retried by the next call
+                if (!c->zero_row) {
+                    void* z = nullptr;
+                    if (devalloc::malloc_retry(&z, (size_t)c->N * 8) == hipSuccess) {
+                        if (hipMemset(z, 0, (size_t)c->N * 8) == hipSuccess) c->zero_row = (u64*)z;
+                        else { (void)hipGetLastError(); (void)hipFree(z); }
+                    } else (void)hipGetLastError();
+                }
+                if (!c->zero_row) return fail(TFHE_E_NOMEM, "allocating the zero row failed");
+            }
             const u64 P = c->q[Lk - 1];
             for (int j = 0; j < level; j++) A.pinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
             const unsigned it1 = (unsigned)batch, it2 = (unsigned)(batch * level);
@@ -1388,20 +1423,24 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
     if (prelifted && (rotate || special || !ks_prelift_ok(c, level))) return fail(TFHE_E_UNSUPPORTED, "internal: pre-lifted rows need the fused key switch");
     const int nw = special ? level + 1 : level;
     const size_t N = (size_t)c->N;
-    // chunk the batch so that the digit tensor stays at a few hundred MiB
-    const size_t per_ct = ((size_t)2 * nw + (size_t)level * nw + (rotate ? (size_t)polys * level : 0)) * N * 8;
+    const bool f14 = ks_fused14(c, Lk, level, special);
+    // chunk the batch so that the digit tensor stays at a few GiB.  The fused key switches (ks_fused14) never write the digit
+    // rows: at N = 2^15 the "digit" buffer only carries the sub-block sums T (2 nw rows per ciphertext), so a whole batch is one
+    // launch (cfg#3, 512 ciphertexts: 248 + 248 + 16 before -- the 16 ran as two nearly empty item rounds of k_ks_fused_sub)
+    const size_t dig_rows = f14 ? (size_t)2 * nw : (size_t)level * nw;
+    const size_t per_ct = ((size_t)2 * nw + dig_rows + (rotate ? (size_t)polys * level : 0)) * N * 8;
     int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)((8192ull << 20) / per_ct)}));
     void* ws = nullptr;
-    // NTT of N > 2^14 uses the context workspace as well: keep ours separate by over-allocating
-    const size_t ntt_tmp = c->logN > 14 ? (size_t)chunk * std::max(2, level) * nw * N * 8 : 0;
-    const bool f14 = ks_fused14(c, Lk, level, special);
+    // NTT of N > 2^14 uses the context workspace as well: keep ours separate by over-allocating (the fused paths run no
+    // stand-alone transform)
+    const size_t ntt_tmp = (c->logN > 14 && !f14) ? (size_t)chunk * std::max(2, level) * nw * N * 8 : 0;
     const size_t evd_bytes = f14 ? (size_t)level * 2 * nw * N * 8 : 0;  // the key rows of this call as doubles
     int rc = ensure_ws(c, ntt_tmp + chunk * per_ct + evd_bytes, &ws);
     if (rc) return rc;
     u64* base = (u64*)((char*)ws + ntt_tmp);
     u64* acc = base;
     u64* dig = acc + (size_t)chunk * 2 * nw * N;
-    u64* rot = dig + (size_t)chunk * level * nw * N;
+    u64* rot = dig + (size_t)chunk * dig_rows * N;
     u64* evd = nullptr;
     if (f14) {
         evd = (u64*)((char*)ws + ntt_tmp + chunk * per_ct);
@@ -1581,15 +1620,28 @@ int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
                            (eval_form ? (need_lf ? (size_t)R * 2 * level : 0) + (size_t)R * 2 : 0)) * N * 8;
     // The keys of all R rotations are read once per chunk (2.8 GB at N = 2^16, 6 limbs + special prime, 63 rotations): a chunk as
     // large as the memory allows (32 GiB of workspace unless TFHE_MD_WS_GIB says otherwise; halved while the allocation fails)
-    static const size_t ws_cap = [] { const char* e = getenv("TFHE_MD_WS_GIB"); const long g = e ? atol(e) : 0; return (size_t)(g > 0 ? g : 32) << 30; }();
+    static const size_t ws_cap_env = [] { const char* e = getenv("TFHE_MD_WS_GIB"); const long g = e ? atol(e) : 0; return (size_t)(g > 0 ? g : 32) << 30; }();
+    // ... and never more than half of what the device has free right now (counting what this context and the allocator's cache
+    // already hold, both of which the allocation below can reuse): other contexts, BFV plans and processes keep their room
+    size_t ws_cap = ws_cap_env;
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            uint64_t cached = 0;
+            tfhe_alloc_stats(nullptr, &cached, nullptr, nullptr);
+            ws_cap = std::min(ws_cap, std::max<size_t>((fr + c->ws_bytes + (size_t)cached) / 2, (size_t)1 << 30));
+        } else (void)hipGetLastError();
+    }
     int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)(ws_cap / per_ct)}));
     size_t ntt_tmp = 0;
     void* ws = nullptr;
     int rc;
+    ws_guard_t ws_guard{c};   // a workspace above ws_keep_bytes() is this call's: back to the allocator on every return path
     for (;;) {
         const size_t ntt_rows = (size_t)chunk * std::max<size_t>({(size_t)level * nw, (size_t)R * 2 * nw, (size_t)2 * level});
         ntt_tmp = c->logN > 14 ? ntt_rows * N * 8 : 0;
-        rc = ensure_ws(c, ntt_tmp + chunk * per_ct, &ws);
+        const size_t need = ntt_tmp + chunk * per_ct;
+        rc = ensure_ws(c, need, &ws, need > ws_keep_bytes());
         if (rc != TFHE_E_NOMEM || chunk == 1) break;
         chunk = (chunk + 1) / 2;
     }

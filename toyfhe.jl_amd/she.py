@@ -22,6 +22,8 @@ from . import native
 from .native import BfvPlan, DeviceBuffer, UsageError
 from .ring import NegacyclicRing, RingElement
 
+DOT_MAX = 64   # operands / rotations one device pass of tfhe_dot, tfhe_lincomb[_many], tfhe_matmul_diag takes (TFHE_DOT_MAX, csrc/kernels.h)
+
 # --------------------------------------------------------------------------------------------------
 # samplers (poly.jl:7-23, crt.jl:146-148,277-279, bgv.jl:27-34)
 # --------------------------------------------------------------------------------------------------
@@ -134,6 +136,20 @@ class BFVParams(SHESchemeParams):
         if self._plan is None:
             self._plan = BfvPlan(self.ring.ctx, self.ring_big.ctx, self.t, self.ring.idx, self.ring_big.idx)
         return self._plan
+
+    def mul_expand(self, c: RingElement) -> RingElement:
+        """mul_expand for one component, bfv.jl:34: switch(ℛbig, c) (:202-226) -- the centred lift q -> Qbig, exact."""
+        n = c.count
+        out = DeviceBuffer(n * self.ring_big.L * self.ring_big.N)
+        self.plan().expand(c.coeffs_primal().ptr, out.ptr, n)
+        return RingElement(self.ring_big, out, None, c.batch)
+
+    def mul_contract(self, e: RingElement) -> RingElement:
+        """mul_contract for one component, bfv.jl:35-40: switch(ℛ, multround(e, t, q)) -- round-ties-away(t e / q), exact."""
+        n = e.count
+        out = DeviceBuffer(n * self.ring.L * self.ring.N)
+        self.plan().contract(e.coeffs_primal().ptr, out.ptr, n)
+        return RingElement(self.ring, out, None, e.batch)
 
     def encode(self, plain) -> RingElement:
         """π⁻¹, bfv.jl:21-24: Δ * plaintext (a list of coefficients, or a list of such lists = a batch)."""
@@ -436,6 +452,12 @@ class CipherText:
         rows = [[float(w) for w in row] for row in weight_rows]
         if not cts or not rows or any(len(r) != len(cts) for r in rows):
             raise AssertionError("lincomb: as many ciphertexts as weights, at least one")
+        if len(cts) > DOT_MAX:      # a device pass takes DOT_MAX operands: longer sums as partial sums (the same residues: + is exact)
+            parts = [CipherText.lincomb_many(cts[k:k + DOT_MAX], [r[k:k + DOT_MAX] for r in rows]) for k in range(0, len(cts), DOT_MAX)]
+            outs = parts[0]
+            for more in parts[1:]:
+                outs = [a + b for a, b in zip(outs, more)]
+            return outs
         c0 = cts[0]
         c0._need_scale()
         ring, n, batch = c0.ring(), c0[0].count, c0[0].batch
@@ -588,7 +610,16 @@ def enc_mul(c1: CipherText, c2: CipherText):
     sz = ring.L * ring.N
     if isinstance(params, BFVParams):
         if len(c1) != 2 or len(c2) != 2:
-            raise NotImplementedError("BFV enc_mul on the device takes 2-element ciphertexts")
+            # any component counts (rlwe_she.jl:247-262 as written: e.g. (c*c)*c without relinearisation): mul_expand per
+            # component (bfv.jl:34), the convolution over ℛbig, mul_contract per output component (bfv.jl:35-40).  The
+            # conversions order ℛ's and ℛbig's streams themselves (tfhe_bfv_expand / tfhe_bfv_contract).
+            e1, e2 = [params.mul_expand(c) for c in c1.cs], [params.mul_expand(c) for c in c2.cs]
+            cs = [None] * (len(e1) + len(e2) - 1)
+            for i, x in enumerate(e1):
+                for j, y in enumerate(e2):
+                    p = x * y
+                    cs[i + j] = p if cs[i + j] is None else cs[i + j] + p
+            return tuple(params.mul_contract(c) for c in cs)
         a, b = _pack([c.coeffs_primal() for c in c1.cs], ring, n), _pack([c.coeffs_primal() for c in c2.cs], ring, n)
         out = DeviceBuffer(n * 3 * sz)
         params.plan().mul(a.ptr, b.ptr, out.ptr, n)
@@ -789,6 +820,14 @@ def matmul_diag(gks, diags, c: CipherText) -> CipherText:
     c._need_scale()
     ring, n, batch = c[0].ring, c[0].count, c[0].batch
     level = ring.L
+    if len(gks) > DOT_MAX:          # a device call takes DOT_MAX rotations: more of them as partial products (+ is exact); the
+        dl = diags.split([1] * diags.count) if isinstance(diags, RingElement) else list(diags)   # later ones weigh c itself by 0
+        if len(dl) != len(gks) + 1:
+            raise AssertionError("matmul_diag: one diagonal for the ciphertext itself and one per rotation")
+        out = matmul_diag(gks[:DOT_MAX], dl[:DOT_MAX + 1], c)
+        for k in range(DOT_MAX, len(gks), DOT_MAX):
+            out = out + matmul_diag(gks[k:k + DOT_MAX], [ring.zero()] + dl[k + 1:k + DOT_MAX + 1], c)
+        return out
     stacked = isinstance(diags, RingElement)              # one batched element holding the len(gks) + 1 diagonals back to back
     if stacked:
         if diags.ring != ring or diags.count != len(gks) + 1:
