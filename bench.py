@@ -16,7 +16,12 @@ After the headline line's legs, rank 0 of a single-GPU run also measures the oth
 (`other_configs`: cfg#3 / #4 / #5 key switch, rotation and rescale rates, N = 2^16 and 60-bit NTT rates, each case checked
 against the oracle on one ciphertext before it is timed -- tools/bench_configs.py); `--no-configs` skips that leg.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu] [--no-ntt] [--no-gather] [--no-configs]
+A multi-rank run (--gpus N > 1) also carries `configs_multi`: the configurations BASELINE.json defines across the GPUs of a node --
+cfg#4 (4096 key switches sharded over the ranks, strong scaling) and cfg#5 (the ciphertext sets of the MNIST test set sharded over
+the ranks) -- each with per-rank rates, max/min imbalance, nranks_seen and the final gather timed on its own.  `--config cfg3|cfg4|cfg5`
+makes one of them THE line of the run instead of the BFV metric.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config bfv|cfg3|cfg4|cfg5] [--no-cpu] [--no-ntt] [--no-gather] [--no-configs]
 """
 import argparse
 import hashlib
@@ -52,6 +57,11 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="ciphertext pairs in the all-core CPU sample (0 = auto)")
     ap.add_argument("--cabi-gather", action="store_true",
                     help="time the final gather through the C ABI (tfhe_gather, the library's own RCCL communicator) instead of torch.distributed")
+    ap.add_argument("--config", default="bfv", choices=["bfv", "cfg3", "cfg4", "cfg5"],
+                    help="what the line measures: bfv = the BASELINE metric (configs[1]); cfg3 / cfg4 / cfg5 = the other BASELINE.json "
+                         "configurations as multi-rank jobs (tools/bench_configs.py MULTI: cfg#4 = 4096 key switches sharded over the ranks, "
+                         "cfg#5 = the MNIST test set's ciphertext sets sharded over the ranks)")
+    ap.add_argument("--total", type=int, default=0, help="--config cfg*: global units instead of the configuration's own (tests)")
     ap.add_argument("--backend", default=os.environ.get("TFHE_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend; 'gloo' + ranks sharing a GPU is a functional check only")
     return ap.parse_args()
@@ -125,6 +135,24 @@ def main():
         tdist.init(backend=args.backend)
     coll_dev = dev if args.backend == "nccl" else None
     tf.native.check(tf.native.lib().tfhe_set_device(dev_index))
+
+    if args.config != "bfv":
+        # one of the other BASELINE.json configurations as THE line of this run (same contract: barrier + sync around exactly
+        # `steps` steps after `warmup`, max over ranks, whole-job rate)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs                                        # imports oracle.ref_cpu as the checker of each rank's shard
+        rec = bench_configs.multi_case(args.config, tdist, world, rank, coll_dev, steps=args.steps, warmup=args.warmup, total=args.total or None,
+                                       gather="cabi" if args.cabi_gather else "torch", backend=args.backend)
+        if rank == 0:
+            line = {"metric": f"{rec.get('unit', '')} -- {rec['config']}", "value": rec.get("value"), "unit": rec.get("unit"), "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec.get("ms_per_step"), "higher_is_better": True,
+                    "scaling": rec.get("scaling"), "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                    "config": {"workload": rec["config"], "global_units": rec.get("global_units"), "sharding": f"units x{world}, no data-path collective"}}
+            line.update({k: v for k, v in rec.items() if k not in line and k != "config"})
+            print(json.dumps(line))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     N = 1 << LOGN
     primes = prime_chain(tf, 50, LBIG, N)
@@ -354,6 +382,23 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs                                        # imports oracle.ref_cpu as the checker of each case
         result["other_configs"] = bench_configs.run(args.configs_scale)
+
+    # ---- multi-rank runs: the configurations BASELINE.json defines across the GPUs of a node (cfg#4 strong-scaled key switches,
+    # cfg#5 the MNIST test set), every rank on its shard; a failure anywhere is a record with "error", never a lost line ------------
+    if world > 1 and not args.no_configs:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+            multi = []
+            for cfg, st_, wu_ in (("cfg4", 5, 2), ("cfg5", 1, 1)):
+                r_ = bench_configs.multi_case(cfg, tdist, world, rank, coll_dev, steps=st_, warmup=wu_, total=(args.total or None) if cfg == "cfg4" else (512 * world if args.total else None),
+                                              gather="cabi" if args.cabi_gather else "torch", backend=args.backend)
+                if rank == 0:
+                    multi.append(r_)
+            if rank == 0:
+                result["configs_multi"] = multi
+        except Exception as e:                                          # noqa: BLE001
+            result.setdefault("errors", []).append(f"configs_multi: {type(e).__name__}: {e}")
 
     for enabled, leg in ((rank == 0 and not args.no_ntt, ntt_record), (rank == 0 and world == 1 and not args.no_cpu, cpu_record),
                          (rank == 0 and world == 1 and not args.no_configs, configs_record)):

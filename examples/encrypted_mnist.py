@@ -157,6 +157,8 @@ def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=Fal
     W2 = np.vstack([model["fq2_w"], np.zeros((54, 64))])
     cache = {} if (repeat > 1 or fused) else None                 # pre-encoded weight plaintexts, filled by the first pass
     for rep in range(repeat):
+      ev0, ev1 = tf.Event(), tf.Event()                             # device-side span of the pass next to the host's clock
+      ev0.record(cring.ctx)
       t0 = time.perf_counter()
       conved = []
       if fused:        # the 4 x 49 scalar-weighted terms in one device pass per component over the 49 inputs (tfhe_lincomb_many)
@@ -184,12 +186,15 @@ def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=Fal
       fq1 = tf.modswitch(fq1.add_plain(np.repeat(model["fq1_b"], B)))
       sq2 = tf.modswitch(tf.keyswitch(ek, fq1 * fq1))
       res = encrypted_matmul(gk, W2, sq2, B, cache, fused).add_plain(np.repeat(np.concatenate([model["fq2_b"], np.zeros(54)]), B))
+      ev1.record(res[0].ring.ctx)
+      t_enq = time.perf_counter() - t0                                # every launch of the circuit is enqueued; the device may still be running
       dec = tf.ckks_decode(tf.decrypt(kp, res), res.scale).real       # [K][N/2]
       got = dec.reshape(K, 64, B)[:, :10].transpose(1, 0, 2).reshape(10, K * B)
       t_eval = time.perf_counter() - t0
     err = float(np.abs(got - want).max())
     if stats is not None:   # (tools/bench_configs.py)
-        stats.update(images=K * B, eval_s=t_eval, setup_s=t_setup, images_per_s=K * B / t_eval)
+        stats.update(images=K * B, eval_s=t_eval, setup_s=t_setup, images_per_s=K * B / t_eval, host_enqueue_s=t_enq,
+                     device_span_s=ev0.elapsed_ms(ev1) * 1e-3)
     if verbose:
         print(f"N=2^{logn}, {K} x {B} images: setup {t_setup:.2f} s, encrypted evaluation {t_eval:.2f} s = {K * B / t_eval:.0f} images/s "
               f"(49 encrypted inputs, 5 x 63 {'hoisted ' if hoisted else ''}rotations, 5 relinearisations per ciphertext set"

@@ -252,7 +252,9 @@ int tfhe_bfv_plan_set_chunk(tfhe_bfv_plan *plan, int chunk);
  * library path), so single-GPU use has no RCCL dependency.
  *   tfhe_comm_id     : rank 0 creates the 128-byte rendezvous id; the host side (MPI.jl / Distributed / torch.distributed)
  *                      hands it to every rank.
- *   tfhe_comm_create : collective over the ranks (after tfhe_set_device on each).
+ *   tfhe_comm_create : collective over the ranks (after tfhe_set_device on each).  The rendezvous has a deadline
+ *                      (TFHE_COMM_TIMEOUT_S, default 180 s): a rank that never joins is a TFHE_E_HIP with the story in
+ *                      tfhe_last_error, not a hung job.
  *   tfhe_gather      : dst [nranks][words_per_rank] <- every rank's src [words_per_rank]; equal shard sizes (pad the last). */
 int tfhe_comm_id(void *id_out /* 128 bytes */);
 int tfhe_comm_create(const void *id, int nranks, int rank, tfhe_comm **out);

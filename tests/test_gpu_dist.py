@@ -90,7 +90,11 @@ def test_two_ranks_run_the_engine_on_their_shards():
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["same_as_single_rank"] and res["oracle"] and res["counts"] == [4, 3] and res["world"] == 2
-    assert res["cabi_gather"] in (None, True)        # None on a 1-GPU box (RCCL refuses two ranks on one device)
+    import torch
+    if torch.cuda.device_count() >= 2:                # two physical devices: the C-ABI communicator MUST come up and agree
+        assert res["backend"] == "nccl" and res["cabi_gather"] is True, res
+    else:
+        assert res["cabi_gather"] is None            # 1-GPU box (RCCL refuses two ranks on one device): gloo, no C-ABI gather
 
 
 def test_cabi_gather_world_of_one():
@@ -118,9 +122,39 @@ def test_bench_spawns_the_ranks_it_is_asked_for():
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64",
-           "--no-cpu", "--no-ntt", "--backend", backend]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+           "--no-cpu", "--no-ntt", "--backend", backend, "--total", "96"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 128 and res["value"] > 0
     assert res["scaling"] == "weak" and "gather" in res and res["gather"]["value_with_gather"] <= res["value"] * 1.0001
+    # the configurations BASELINE.json defines across the GPUs of a node ride in the same line (here scaled down by --total)
+    multi = {m["config"][:5]: m for m in res["configs_multi"]}
+    assert set(multi) == {"cfg#4", "cfg#5"} and not any("error" in m for m in multi.values()), multi
+    c4 = multi["cfg#4"]
+    assert c4["global_units"] == 96 and [r["units"] for r in c4["per_rank"]] == [48, 48] and c4["nranks_seen"] == 2
+    assert c4["value"] > 0 and c4["imbalance_max_over_min"] >= 1.0 and c4["gather"] and "error" not in c4["gather"]
+    c5 = multi["cfg#5"]
+    assert [r["sets"] for r in c5["per_rank"]] == [1, 1] and c5["value"] > 0 and c5["global_units"] == 1024
+
+
+@pytest.mark.parametrize("cfg,total,units", [("cfg4", 67, [34, 33]), ("cfg3", 8, [8, 8]), ("cfg5", 1024, [1, 1])])
+def test_bench_multi_rank_modes_of_the_other_configurations(cfg, total, units):
+    """`bench.py --gpus 2 --config cfg4|cfg3|cfg5`: the configuration is THE line of the run -- every rank on its shard (ragged for
+    cfg#4), each rank's shard checked against the oracle before it is timed, per-rank rates, imbalance, the final gather timed
+    separately.  RCCL with two GPUs; both ranks on GPU 0 over gloo on a 1-GPU box (functional check)."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", cfg, "--steps", "2", "--warmup", "1",
+           "--total", str(total), "--backend", backend]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "error" not in res, res
+    assert res["n_gpus"] == 2 and res["nranks_seen"] == 2 and res["value"] > 0 and res["steps"] == 2 and res["warmup"] == 1
+    key = "sets" if cfg == "cfg5" else "units"
+    assert [r[key] for r in res["per_rank"]] == units
+    assert res["scaling"] == ("weak" if cfg == "cfg3" else "strong")
+    if cfg != "cfg5":
+        assert res["gather"] and "error" not in res["gather"] and res["gather"]["value_with_gather"] <= res["value"] * 1.0001

@@ -212,3 +212,39 @@ def test_sampler_hook_is_a_rand_method():
     src = open(SHIM).read()
     assert re.search(r"function Random\.rand\(rng::HipRng, r::RingSampler\{ℛ\}\)", src)
     assert "mutable struct HipRng <: Random.AbstractRNG" in src
+
+
+def test_hoisted_rotation_callers_prepare_their_keys():
+    """tfhe_matmul_diag has no `prepared = 0` fallback -- every shim function that calls it must take its key
+    pointers from `prepared(gk)` (tfhe_galois_key_prepare), and tfhe_rotate_many must say prepared = 1 when it does the same."""
+    src = open(SHIM).read()
+    assert "tfhe_galois_key_prepare" in {c[0] for c in shim_ccalls()}
+    for m in re.finditer(r"^function (\w+)\(.*?^end", src, flags=re.S | re.M):
+        body = m.group(0)
+        if ":tfhe_matmul_diag" in body:
+            assert "prepared(gk)" in body and "pack(gk.key)" not in body, m.group(1)
+            assert "squared_encoding" in body, "a ciphertext-by-plaintext product leaves at the squared scale (ckksencoding.jl:106-111)"
+        if ":tfhe_rotate_many" in body:
+            uses_prepared = "prepared(gk)" in body
+            flag = re.search(r"length\(ek1\.key\),\s*(\d),\s*gs", body)
+            assert flag and (flag.group(1) == "1") == uses_prepared, "the `prepared` flag must match the keys passed"
+
+
+def test_validation_kit_refers_to_things_that_exist():
+    """toyfhe.jl_amd/julia/test/runtests.jl and tools/gen_reference_fixtures.jl cannot be run here either: at least every
+    `H.name` they use is defined in the shim, every fixture case the generator handles has inputs, and the generator reads
+    exactly the header layout toyfhe.jl_amd/wire.py writes."""
+    shim = open(SHIM).read()
+    defined = set(re.findall(r"\bfunction\s+(?:[\w.]+\.)?([\w!]+)", shim)) | set(re.findall(r"^([\w!]+)\([^=\n]*\)(?:\s+where\s+[^=\n]+)?\s*=(?!=)", shim, flags=re.M))
+    kit = open(os.path.join(ROOT, "toyfhe.jl_amd", "julia", "test", "runtests.jl")).read()
+    used = set(re.findall(r"\bH\.([\w!]+)", kit))
+    assert used and used <= defined, sorted(used - defined)
+    gen = open(os.path.join(ROOT, "tools", "gen_reference_fixtures.jl")).read()
+    ops = set(re.findall(r'op == "(\w+)"', gen)) | set(re.findall(r'"(\w+)"', " ".join(re.findall(r"op in \(([^)]*)\)", gen))))
+    import glob
+    import json
+    have = {json.load(open(p))["op"] for p in glob.glob(os.path.join(ROOT, "tests", "golden", "ref_julia", "*", "case.json"))}
+    assert have and have <= ops, sorted(have - ops)
+    from toyfhe_jl_amd import wire
+    assert wire._HDR.format == "<8sIIIIIIQQiI" and wire._HDR.size == 56     # magic, 6 x u32, 2 x u64, i32, u32: what readblob / writeblob move
+    assert gen.count("read(io, UInt32)") >= 2 and "TFHEWIRE" in gen

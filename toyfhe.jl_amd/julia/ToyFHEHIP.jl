@@ -322,6 +322,19 @@ function pack(ek::KeySwitchKey)
         pack(hipring(ℛk), parts, eltype(ℛk))
     end
 end
+# Galois keys PREPARED for the hoisted rotations (tfhe_rotate_many with prepared = 1, tfhe_matmul_diag): every NTT-domain row
+# permuted by g^-1 (tfhe_galois_key_prepare), once per key -- what GaloisKey.prepared() is in the Python mirror.
+const PREPARED_KEYS = IdDict{Any,HipVector}()
+function prepared(gk::ToyFHE.GaloisKey)
+    get!(PREPARED_KEYS, gk) do
+        ek = gk.key; key = pack(ek); keyring = NTT.ring(ek.key[1].mask); ctx = hipring(keyring)
+        out = HipVector{eltype(keyring)}(key.limbs, key.n, key.count); on(ctx, (out,), (key,))
+        GC.@preserve key out check(ccall((:tfhe_galois_key_prepare, lib), Cint,
+                    (Ptr{Cvoid}, Cint, Cint, UInt64, Ptr{UInt64}, Ptr{UInt64}),
+                    ctx.handle, nlimbs(eltype(keyring)), length(ek.key), gk.galois_element, key.ptr, out.ptr))
+        out
+    end
+end
 # unpack: `polys` (batched) ring elements of ℛ from a packed [count][polys][limbs][N] buffer; dual = true: NTT-domain results
 function unpack(ctx::HipRing, buf::HipVector, ℛ, polys::Integer; dual::Bool=false)
     T = eltype(ℛ); limbs = nlimbs(T); n = degree(ℛ); cnt = buf.count
@@ -399,11 +412,11 @@ function rotate_many(gks::Vector{<:ToyFHE.GaloisKey}, c::CipherText{Enc,P,<:Ring
     @assert length(c.cs) == 2
     ek1 = gks[1].key; keyring = NTT.ring(ek1.key[1].mask); Lk = nlimbs(eltype(keyring)); level = nlimbs(T); cnt = batchsize(c)
     ctx = hipring(keyring); ct = pack(ctx, c); n = degree(ℛ); nrot = length(gks)
-    packed = HipVector[pack(gk.key) for gk in gks]; out = HipVector{T}(2 * level, n, cnt * nrot); on(ctx, (out,), (ct, packed...))
+    packed = HipVector[prepared(gk) for gk in gks]; out = HipVector{T}(2 * level, n, cnt * nrot); on(ctx, (out,), (ct, packed...))
     keys = Ptr{UInt64}[k.ptr for k in packed]; gs = UInt64[gk.galois_element for gk in gks]
     GC.@preserve packed ct out check(ccall((:tfhe_rotate_many, lib), Cint,
                 (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Ptr{UInt64}}, Cint, Cint, Ptr{UInt64}, Cint, Ptr{UInt64}, Ptr{UInt64}, Int64),
-                ctx.handle, Lk, level, ek1.params isa ModulusRaised ? 1 : 0, keys, length(ek1.key), 0, gs, nrot,
+                ctx.handle, Lk, level, ek1.params isa ModulusRaised ? 1 : 0, keys, length(ek1.key), 1, gs, nrot,
                 ct.ptr, out.ptr, cnt))
     map(1:nrot) do r                                             # out: [nrot][cnt][2][level][N]
         part = HipVector{T}(2 * level, n, cnt); on(ctx, (part,), (out,))
@@ -420,9 +433,10 @@ end
 function matmul_diag(gks::Vector{<:ToyFHE.GaloisKey}, diags::Vector{<:RingElement{ℛ,T,<:HipVector}},
                      c::CipherText{Enc,P,<:RingElement{ℛ,T,<:HipVector}}) where {Enc,P,ℛ,T}
     @assert length(c.cs) == 2 && !isempty(gks) && length(diags) == length(gks) + 1
+    length(gks) <= 64 || throw(ToyFHE.UsageError("matmul_diag: at most 64 rotations per call (TFHE_DOT_MAX); split the product and add the parts"))
     ek1 = gks[1].key; keyring = NTT.ring(ek1.key[1].mask); Lk = nlimbs(eltype(keyring)); level = nlimbs(T); cnt = batchsize(c)
     ctx = hipring(keyring); ct = pack(ctx, c); n = degree(ℛ); nrot = length(gks)
-    packed = HipVector[pack(gk.key) for gk in gks]
+    packed = HipVector[prepared(gk) for gk in gks]                # tfhe_matmul_diag takes PREPARED keys only (tfhe_galois_key_prepare)
     dparts = HipVector[coeffs_dual(d).parent for d in diags]
     all(d -> d.count == 1, dparts) || throw(ToyFHE.UsageError("matmul_diag: one polynomial per diagonal"))
     dg = HipVector{T}(level, n, nrot + 1); on(ctx, (dg,), (dparts...,))
@@ -436,8 +450,12 @@ function matmul_diag(gks::Vector{<:ToyFHE.GaloisKey}, diags::Vector{<:RingElemen
                 (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Ptr{UInt64}}, Cint, Ptr{UInt64}, Cint, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Int64),
                 ctx.handle, Lk, level, ek1.params isa ModulusRaised ? 1 : 0, keys, length(ek1.key), gs, nrot,
                 dg.ptr, ct.ptr, out.ptr, cnt))
-    CipherText{Enc}(c.params, unpack(ctx, out, ℛ, 2; dual=true))
+    # a ciphertext-by-plaintext product: the result sits at the SQUARED scale, as the reference's `.*` returns it
+    # (ckksencoding.jl:106-111: CipherText{CKKSEncoding{Tscale^2}}); other encodings carry no scale
+    CipherText{squared_encoding(Enc)}(c.params, unpack(ctx, out, ℛ, 2; dual=true))
 end
+squared_encoding(::Type{CKKSEncoding{Tscale}}) where {Tscale} = CKKSEncoding{Tscale^2}
+squared_encoding(::Type{E}) where {E} = E
 
 # ---- CKKS encode / decode (ckksencoding.jl:56-97) on the device --------------------------------------------------------
 # denom = mant * 2^exp2 with a 64-bit mant (exact for 2^k and for integers below 2^64 times 2^k; to 2^-63 otherwise)
@@ -498,12 +516,34 @@ function plan(params::BFVParams)
 end
 function ToyFHE.enc_mul(c1::CipherText{E,BFVParams,<:RingElement{ℛ,T,<:HipVector}}, c2::CipherText{E,BFVParams}) where {E,ℛ,T}
     c1.params !== c2.params && throw(ToyFHE.UsageError("Attempting to multiply ciphertexts with differing parameters"))
-    (length(c1.cs) == 2 && length(c2.cs) == 2) || error("BFV enc_mul on the device takes 2-element ciphertexts")
+    # any other component counts: the reference's generic convolution (rlwe_she.jl:247-262) over the device hooks below
+    (length(c1.cs) == 2 && length(c2.cs) == 2) || return invoke(ToyFHE.enc_mul, Tuple{Any,Any}, c1, c2)
     ctx = hipring(ℛ); a, b = pack(ctx, c1), pack(ctx, c2); cnt = samecount(a, b)   # the plan's results are ordered on ℛ's stream
     out = HipVector{T}(3 * nlimbs(T), degree(ℛ), cnt); on(ctx, (out,), (a, b))
     GC.@preserve a b out check(ccall((:tfhe_bfv_mul, lib), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}, Int64),
                 plan(c1.params).handle, a.ptr, b.ptr, out.ptr, cnt))
     unpack(ctx, out, ℛ, 3)
+end
+# mul_expand / mul_contract (bfv.jl:34-40) for device storage: switch(ℛbig, c) and switch(ℛ, multround(e, t, q)) per component
+# (tfhe_bfv_expand / tfhe_bfv_contract: exact, bit-identical to the BigInt path); the ring products in between are ℛbig's own
+# device NTTs.  The conversions order ℛ's and ℛbig's streams themselves.
+function bfv_expand(params::BFVParams, x::RingElement{ℛ,T,<:HipVector}) where {ℛ,T}
+    ℛb = params.ℛbig; Tb = eltype(ℛb); src = coeffs_primal(x).parent
+    out = HipVector{Tb}(nlimbs(Tb), degree(ℛb), src.count); on(hipring(ℛb), (out,), (src,))
+    GC.@preserve src out check(ccall((:tfhe_bfv_expand, lib), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Int64),
+                plan(params).handle, src.ptr, out.ptr, src.count))
+    RingElement{ℛb}(OffsetArray(out, 0:degree(ℛb)-1), nothing)
+end
+function bfv_contract(params::BFVParams, e::RingElement{ℛb,Tb,<:HipVector}) where {ℛb,Tb}
+    ℛ = params.ℛ; T = eltype(ℛ); src = coeffs_primal(e).parent
+    out = HipVector{T}(nlimbs(T), degree(ℛ), src.count); on(hipring(ℛ), (out,), (src,))
+    GC.@preserve src out check(ccall((:tfhe_bfv_contract, lib), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt64}, Int64),
+                plan(params).handle, src.ptr, out.ptr, src.count))
+    RingElement{ℛ}(OffsetArray(out, 0:degree(ℛ)-1), nothing)
+end
+ToyFHE.mul_expand(params::BFVParams, c::CipherText{E,BFVParams,<:RingElement{ℛ,T,<:HipVector}}) where {E,ℛ,T} = map(x -> bfv_expand(params, x), c.cs)
+function ToyFHE.mul_contract(params::BFVParams, c::Vector{<:RingElement{ℛb,Tb,<:HipVector}}) where {ℛb,Tb}
+    map(e -> bfv_contract(params, e), c)
 end
 # c1*c2 followed by keyswitch(ek, .) in one call (the BASELINE.json unit) for RNS-gadget keys on ℛ itself
 function mul_relin(ek::KeySwitchKey, c1::CipherText{E,BFVParams,<:RingElement{ℛ,T,<:HipVector}}, c2::CipherText{E,BFVParams}) where {E,ℛ,T}
