@@ -273,6 +273,17 @@ def main():
                       "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_LDS"):
                 if all(k in v for v in fused.values()):
                     sq[k + "_per_ctmul"] = per_ct(k)
+    # (3) the same on the USEFUL-work scale: only the butterflies (8 fp64 instructions each: one 6-instruction modular
+    # product, one sum, one difference) and the modular products of the tensor / key inner product (6 + 1 accumulate) count --
+    # range sweeps, conversions, address arithmetic and moves do not.  Per ciphertext-mul: 17 limbs x 7 + 8 limbs x 10 = 199 limb
+    # transforms of 14 x 2^13 butterflies, 17 x 4 tensor products and 8 x 8 x 2 key products per coefficient.
+    ess_per_ct = (LBIG * 7 + L * (L + 2)) * LOGN * (N // 2) * 8 / 64.0 + LBIG * 4 * N * 6 / 64.0 + L * L * 2 * N * 7 / 64.0   # wave64 instructions
+    essential_frac = ess_per_ct * B * args.steps / ntt_s / 1e9 / VALU_PEAK_GIPS if ntt_s > 0 else None
+    # (4) on SURVEY 8(d)'s own unit: a ciphertext-mul moves 6 L N 8 = 6 MiB compulsory bytes (4 polynomials in, 2 out)
+    ctmul_bytes = 6 * L * N * 8
+    traffic_per_ctmul = None
+    if pmc and not pmc_stale:
+        traffic_per_ctmul = sum(v.get("hbm_bytes", 0.0) for v in pmc["kernels"].values()) / pmc["batch"]    # every kernel of the step
     roof = {
         "bound": "valu-fp64" if valu_frac is not None else "hbm",
         "kernel": "k_bfv_core_fused + k_ks_fused: the 2^14-point negacyclic NTTs (exact-integer fp64 butterflies) fused with the "
@@ -284,6 +295,12 @@ def main():
         "frac": valu_frac if valu_frac is not None else teq / HBM_PEAK_GBS,
         "valu_issue_util_profiled_pass": valu_frac_clk, "profiled_clock_GHz": clock_ghz,
         "hbm_frac": hbm_frac,
+        "essential_frac": essential_frac, "essential_wave_instr_per_ctmul": ess_per_ct,
+        "essential_note": "butterflies (8 fp64 instructions) + tensor / key products only, / kernel time of the two fused kernels / 614.4 G/s: "
+                          "the fraction of the fp64 vector peak spent on arithmetic the algorithm needs (frac counts every issued VALU instruction)",
+        "ctmul_hbm_frac": value / max(1, world) * ctmul_bytes / 1e9 / HBM_PEAK_GBS,
+        "ctmul_algorithmic_bytes": ctmul_bytes, "traffic_per_ctmul": traffic_per_ctmul,
+        "traffic_per_ctmul_over_algorithmic": (traffic_per_ctmul / ctmul_bytes) if traffic_per_ctmul else None,
         "traffic": traffic,
         "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the two kernels, profiles/pmc_bench_kernels.json, "
                         "scaled to this run's launches)",

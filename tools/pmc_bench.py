@@ -31,10 +31,19 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
         continue
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        seen = set()
-        for r in csv.DictReader(open(f)):
+        rows = list(csv.DictReader(open(f)))
+        # steady state: the profiled command runs 3 warm-up steps before the counted one; the dispatches of each
+        # kernel's first step (cold clocks, cold caches) are dropped -- the first quarter of its dispatches in this pass
+        order = collections.defaultdict(list)
+        for r in rows:
             k = short(r["Kernel_Name"])
-            if "k_" not in k:
+            if "k_" in k and int(r["Dispatch_Id"]) not in order[k]:
+                order[k].append(int(r["Dispatch_Id"]))
+        drop = {k: set(sorted(v)[:len(v) // 4]) for k, v in order.items()}
+        seen = set()
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            if "k_" not in k or int(r["Dispatch_Id"]) in drop[k]:
                 continue
             c = r["Counter_Name"]
             kern[k][c] += float(r["Counter_Value"])
@@ -43,7 +52,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
                 seen.add(r["Dispatch_Id"])
                 kern[k]["duration_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 out = {"method": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv, separate passes (FETCH_SIZE | WRITE_SIZE | 8 SQ counters | "
-                 "GRBM_GUI_ACTIVE + SQ_INSTS_LDS/SALU + SQ_WAVES) over `bench.py --steps 1 --warmup 0 --batch 256 --no-cpu --no-ntt`; "
+                 "GRBM_GUI_ACTIVE + SQ_INSTS_LDS/SALU + SQ_WAVES) over `bench.py --steps 1 --warmup 3 --batch 256 --no-cpu --no-ntt` (the first quarter of each kernel's dispatches dropped: steady state); "
                  "FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE x2 (gfx950); per-kernel sums over the launches",
        "batch": batch, "source_id": source_id(), "note": f"{tag}: one launch of each fused kernel covers {batch} ciphertexts", "kernels": {}}
 for k, c in sorted(kern.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):

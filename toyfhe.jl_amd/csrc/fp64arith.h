@@ -24,8 +24,10 @@
 #include "modarith.h"
 
 #define TFHE_FP_QMAX 1126999418470400ull /* 2^50 + 2^40 */
+#ifndef TFHE_FP_A                   /* (overridable for design experiments: plans for a smaller size class of moduli) */
 #define TFHE_FP_A 0.25025          /* >= TFHE_FP_QMAX 2^-52 */
 #define TFHE_FP_LIMIT 7.9           /* < 2^53 / TFHE_FP_QMAX = 7.992 */
+#endif
 
 struct ftw_t {  // twiddle w, an exact integer < p
     double w;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void fwd_schedule(u64* lds, const u64* gsrc, u64* gds
 // AO: the policy whose out_inv_* forms the words of the final store (ArithFpD: reduced doubles instead of canonical words)
 template <class A, int LOGB, int LOGT, int SEND, bool SCALE = true, class AO = A>
 __device__ __forceinline__ void inv_schedule_ptw(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
-                                                 u32 pre, const u64* addend, const typename A::tw* tw_cur) {
+                                                 u32 pre, const u64* addend, const typename A::tw* tw_cur, u64* keep = nullptr) {
     constexpr int K = pass_k_inv(LOGB, LOGT, SEND);
     constexpr int S0 = SEND - K;
     constexpr bool FROM_GLOBAL = (SEND == LOGB), TO_GLOBAL = (S0 == 0);
@@ -71,9 +71,9 @@ __device__ __forceinline__ void inv_schedule_ptw(u64* lds, const u64* gsrc, u64*
         if constexpr (S0 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S0 - K2, K2, false>(tw_next, C, tid, pre);
         inv_store<A, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid, nullptr);
         __syncthreads();
-        inv_schedule_ptw<A, LOGB, LOGT, S0, SCALE, AO>(lds, gsrc, gdst, C, tid, pre, addend, tw_next);
+        inv_schedule_ptw<A, LOGB, LOGT, S0, SCALE, AO>(lds, gsrc, gdst, C, tid, pre, addend, tw_next, keep);
     } else {
-        inv_store<AO, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid, addend);
+        inv_store<AO, LOGB, LOGT, S0, K, FROM_GLOBAL, SCALE>(v, lds, gdst, C, tid, addend, keep);
     }
 }
 
@@ -1764,7 +1764,8 @@ __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, con
 // SCALE = false: the caller has folded N^-1 into its operands (k_ks_fused: into the key rows), the last stage is a plain
 // butterfly instead of two scaling products per pair
 template <class A, int LOGB, int LOGT, bool SCALE = true, bool TWL = false, class AO = A>
-__device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* v, u64* gdst, const typename A::ctx& C, const u64* addend) {
+__device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* v, u64* gdst, const typename A::ctx& C, const u64* addend,
+                                                    u64* keep = nullptr) {
     constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB);
     constexpr int E = 1 << (LOGB - LOGT);
     const u32 tid = fresh_tid();
@@ -1794,7 +1795,119 @@ __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* 
             inv_store<A, LOGB, LOGT, S1, KI1, true, SCALE>(v, lds, nullptr, C, tid);
         }
         __syncthreads();
-        inv_schedule_ptw<A, LOGB, LOGT, S1, SCALE, AO>(lds, nullptr, gdst, C, tid, 1u, addend, tw_next);
+        inv_schedule_ptw<A, LOGB, LOGT, S1, SCALE, AO>(lds, nullptr, gdst, C, tid, 1u, addend, tw_next, keep);
+    }
+}
+
+// N = 2^(LOGB+2) inverse, fp64 policy, ONE kernel with the two TOP stages FIRST (r04): decimation in frequency on the natural-order
+// input.  With k = k' + m M (M = 2^LOGB, m < 4) and i = 4 i' + c:
+//     a[4 i' + c] = N^-1 psi^{-(4i'+c)} sum_k A[k] w^{-ik} = INTT'( B_c )[i'],   B_c[k'] = psi^{-c (2k'+1)} sum_m A[k' + m M] I^{-c m},
+// I = psi^{N/2} (I^2 = -1), INTT' = the M-point negacyclic inverse over psi^4 -- whose twiddle tables are the first quarter of this
+// limb's own (W[k] = psi^brv(k): brv_16(k) = 4 brv_14(k) for k < 2^14) -- scaled by this ring's N^-1.  So the four output classes c
+// are independent M-point transforms of combinations of the four input quarters: the mirror image of k_ntt_fwd_quad.  A
+// workgroup reads the four quarters (LDS-DMA stream, as there), forms the operands of classes 2 ph and 2 ph + 1 (the row's other
+// workgroup -- same XCD, same iteration -- takes the other two and finds the lines in L2), runs the two transforms and stores
+// 16-byte pieces at words 4 i' + 2 ph: one read and one write of the row (2 N 8 bytes) where k_ntt_inv_subpair + k_ntt_inv_top<2>
+// move it twice, and every stored word is a FINAL coefficient (k_ntt_inv_subpair's are sub-block results that still need the top
+// stages of all four sub-blocks).  Out of place only (the sibling reads the same source words).
+//   class 2 ph    : S = (A0 + A2) + sgn (A1 + A3)                      twiddle 1 (ph = 0) / psi^{-2(2k'+1)}
+//   class 2 ph + 1: S = (A0 - A2) + sgn I^-1 (A1 - A3)                 twiddle psi^{-(2k'+1)} / psi^{-3(2k'+1)},   sgn = +1 / -1
+// The per-point twiddles of a thread's points k' = tid + (e << LOGT) follow from its first one by the uniform factor
+// psi^{-c 2^(LOGT+1)} (ntt_limb_t::i2_t0, i2_g): no table loads inside the DMA stream (vmcnt is hand-counted there).
+// Ranges (fp64arith.h): inputs canonical (< p): S <= 4 p, exact; products <= p (1/2 + 1.5 a 4) = 2 p; the transforms reduce first.
+template <class A, int LOGB, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_quad2(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                              const ntt_limb_t* __restrict__ LT, limb_sel_t sel, u32 nitems, u32 limb_mask) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    constexpr int x = 2;
+    constexpr int K1 = pass_k_inv(LOGB, LOGT, LOGB), S1 = LOGB - K1;
+    typedef pgeom<LOGB, LOGT, S1, K1> G1;
+    constexpr int E = G1::E;
+    constexpr int K2 = pass_k_inv(LOGB, LOGT, S1), KL = S1 - K2;  // middle and last pass widths
+    static_assert(KL >= 1 && pass_k_inv(LOGB, LOGT, KL) == KL, "three-pass schedule expected");
+    typedef pgeom<LOGB, LOGT, 0, KL> GL;
+    static_assert(GL::SETS == 1 && GL::LO == LOGT, "last pass: element r of a thread is word tid + (r << LOGT)");
+    static_assert(G1::SETS << (LOGT + K1) == 1 << LOGB, "first pass: register position e <-> point tid + (e << LOGT)");
+    const size_t ntot = (size_t)1 << (LOGB + x);
+    const u32 dmask = dense_mask((u32)sel.n, limb_mask), dn = dense_count(nitems, 1, (u32)sel.n, dmask), niter = (dn + gridDim.x - 1) / gridDim.x;
+    bool first = true;
+    for (u32 it = 0; it < niter; it++) {
+        const u32 item = dense_item(xcd_walk_item(it, blockIdx.x, gridDim.x, x - 1, dn), 1, (u32)sel.n, dmask);
+        if (item == ~0u) continue;
+        const u32 ph = item & 1u, pl = item >> 1, j = pl % (u32)sel.n;
+        if (limb_mask && !((limb_mask >> j) & 1u)) continue;  // the other policy's launch takes this limb
+        const ntt_limb_t& L = LT[sel.idx[j]];
+        typename A::ctx C = A::make(L);
+        C.Winvb = L.i2_winvb;  // boundary pass of the M-point transform over psi^4 (pre = 1: a whole transform of that ring)
+        const u64* s = src + pl * ntot;
+        u64* d = dst + pl * ntot + 2u * ph;
+        typename A::elem w[2][E];  // first-pass operands of the two classes, in the inverse first pass's register map
+        {
+            const u32 tid = fresh_tid();
+            typedef __attribute__((address_space(1))) const double* gptr_t;
+            const gptr_t t0 = (gptr_t)L.i2_t0;
+            // ph = 0: classes 0 (no twiddle: the constant 1 keeps the phase branch-free) and 1;  ph = 1: classes 2 and 3
+            double ta = ph ? t0[(1u << LOGT) + tid] : 1.0;
+            double tb = t0[(ph ? (2u << LOGT) : 0u) + tid];
+            const ftw_t ga{ph ? L.i2_g[1] : 1.0}, gb{ph ? L.i2_g[2] : L.i2_g[0]}, iinv{L.i2_iinv};
+            const double sgn = ph ? -1.0 : 1.0;
+            pin_vgpr(ta);
+            pin_vgpr(tb);  // landed before the DMA stream starts (its waits count DMA instructions only)
+            if (!first) __syncthreads();  // the previous item's last pass has read its LDS image
+            dma_stream_load<LOGB, LOGT, 4, 2>(lds, s, tid, [&](int e, const u64* q) {
+                const int idx = (e % G1::SETS) * G1::R + (int)brev_bits((u32)(e / G1::SETS), K1);
+                const double a0 = fp_from_u64(q[0]), a1 = fp_from_u64(q[1]), a2 = fp_from_u64(q[2]), a3 = fp_from_u64(q[3]);
+                // the twiddle recurrence advances WITH the data: left free, the scheduler runs the (data-independent) chain to its end
+                // ahead of the first DMA wait and parks 2 x 32 twiddles in registers (32 spilled in that form)
+                asm volatile("" : "+v"(ta), "+v"(tb) : "v"(a0));
+                const double slo = fp_fma(sgn, a1 + a3, a0 + a2);
+                const double t = fp_mulmod_c(a1 - a3, iinv, C.p, C.pinv);
+                const double shi = fp_fma(sgn, t, a0 - a2);
+                w[0][idx] = fp_mulmod_c(slo, ftw_t{ta}, C.p, C.pinv);
+                w[1][idx] = fp_mulmod_c(shi, ftw_t{tb}, C.p, C.pinv);
+                ta = fp_mulmod_c(ta, ga, C.p, C.pinv);
+                tb = fp_mulmod_c(tb, gb, C.p, C.pinv);
+            });
+            first = false;
+            TFHE_SCHED_FENCE();  // the first pass's twiddle requests stay behind the load phase (register pressure)
+        }
+        u64 held[E];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const u32 tid = fresh_tid();
+            TFHE_SCHED_FENCE();
+            // the plain three-pass schedule (as k_ntt_inv_subpair; the twiddle prefetch of inv_schedule_ptw costs 62 registers next
+            // to the 64 of the waiting class and the 64 of the held results: 166 spilled in the first version of this kernel)
+            __syncthreads();  // every wave has read the last DMA chunk / the previous transform's last pass has read LDS
+            {
+                typename A::elem* v = w[half];
+#pragma unroll
+                for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], C.p, C.pinv);
+                inv_compute<A, LOGB, LOGT, S1, K1, true, true, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, 1u);
+                inv_store<A, LOGB, LOGT, S1, K1, true, true>(v, lds, nullptr, C, tid);
+            }
+            __syncthreads();
+            ntt_inv_pass<A, LOGB, LOGT, KL, K2, false, false, true>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
+            __syncthreads();
+            {
+                u64 r3[E];
+                typename A::elem v[E];
+                inv_load_data<LOGB, LOGT, 0, KL, false>(r3, lds, nullptr, tid, 0, 0u);
+                inv_compute<A, LOGB, LOGT, 0, KL, false, true, 0>(v, r3, nullptr, C, tid, 1u);
+                if (half == 0) {
+#pragma unroll
+                    for (int r = 0; r < E; r++) held[r] = A::out_inv_scaled(v[r], C);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < E; r++) {
+                        u64x2_t ww;
+                        ww.x = held[r];
+                        ww.y = A::out_inv_scaled(v[r], C);
+                        *(u64x2_t*)(d + ((u64)(tid + ((u32)r << LOGT)) << x)) = ww;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -1992,6 +2105,48 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 u64 op[E];  // first-pass operands of this sub-block (element bits)
                 // (the LDS-DMA streaming of dma_stream_load, which pays in k_ntt_fwd_quad, measured 7-9 % SLOWER here: cfg#3
                 // 32.6 k against 35.1 k key switches/s -- the piece-wise register loads below stay)
+#ifndef TFHE_KS_SUB_PIPE  // 1: the software-pipelined load phase below (X = 1); 0: the piece-wise loads of r01m (comparisons)
+#define TFHE_KS_SUB_PIPE 1
+#endif
+                if constexpr (X == 1 && TFHE_KS_SUB_PIPE) {
+                    // r04.  The piece-wise phase below exposes one L2 / Infinity-Cache round trip per piece: 4 x (16 requests, wait,
+                    // 8 lifts + top-stage products) per digit, 7 of the 28 us a digit takes (-DTFHE_ABL_NOROWS: + 13-18 % on the
+                    // key switch), because the compiler either hoists every request of the phase (spills next to the 128
+                    // accumulator registers) or, fenced, issues a piece only after the previous one has been consumed.  Here the
+                    // requests are inline asm with hand-counted waits (vmcnt is in order): pieces of 4 points (8 requests), three
+                    // pieces in flight while a fourth is being consumed -- 24 requests per thread under the arithmetic of a piece.
+                    // A requested register must not be touched before its wait: the waits take the piece's registers as "+v"
+                    // operands, and the kernel must stay free of spills (checked: scratch 0).
+                    constexpr int PE2 = 4, NP = E / PE2, SLOTS = 4;
+                    u64 q[SLOTS][2][PE2];
+                    const u32 off0 = tid << 3;
+                    auto issue = [&](int h) {
+#pragma unroll
+                        for (int r = 0; r < PE2; r++) {
+                            const u32 off = off0 + ((u32)(h * PE2 + r) << (LOGT + 3));
+                            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(q[h % SLOTS][0][r]) : "v"(off), "s"(grow) : "memory");
+                            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(q[h % SLOTS][1][r]) : "v"(off + (8u << LOGB)), "s"(grow) : "memory");
+                        }
+                    };
+                    issue(0); issue(1); issue(2);
+#pragma unroll
+                    for (int h = 0; h < NP; h++) {
+                        u64(&p)[2][PE2] = q[h % SLOTS];
+                        const int later = (NP - 1 - h) < 2 ? (NP - 1 - h) : 2;   // pieces requested after h and still in flight
+#define TFHE_WAIT_PIECE(n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(p[0][0]), "+v"(p[0][1]), "+v"(p[0][2]), "+v"(p[0][3]), "+v"(p[1][0]), "+v"(p[1][1]), "+v"(p[1][2]), "+v"(p[1][3]) : : "memory")
+                        if (later == 2) TFHE_WAIT_PIECE(16);
+                        else if (later == 1) TFHE_WAIT_PIECE(8);
+                        else TFHE_WAIT_PIECE(0);
+#undef TFHE_WAIT_PIECE
+                        if (h + 3 < NP) issue(h + 3);
+#pragma unroll
+                        for (int r = 0; r < PE2; r++) {
+                            const double lo = A::from_global_lift(p[0][r], C, lf, true), hv = A::from_global_lift(p[1][r], C, lf, true);
+                            const double z = fp_fma(sgn_h, fp_mulmod_c(hv, w1, C.p, C.pinv), lo);
+                            op[h * PE2 + r] = A::to_lds(fp_reduce(z, C.p, C.pinv));
+                        }
+                    }
+                } else {
                 constexpr int PC = 4 * X, PE = E / PC;  // pieces of the load phase (bounds the raw words in flight)
 #pragma unroll
                 for (int h = 0; h < PC; h++) {
@@ -2028,6 +2183,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                         op[h * PE + r] = A::to_lds(fp_reduce(z, C.p, C.pinv));
                     }
                     TFHE_SCHED_FENCE();
+                }
                 }
                 if (!first) __syncthreads();  // the previous transform's last pass has read LDS
                 first = false;

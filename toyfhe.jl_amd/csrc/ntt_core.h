@@ -106,6 +106,13 @@ struct ntt_limb_t {   // per-limb constants (device copy lives in the context)
     const ftwd_t* Winvdb;
     // same idea for the split kernels (a 2^14 transform as two 2^13 half-problems, see k_ntt_fwd_split14): the
     // boundary pass of each half permuted within its half of every stage block
+    // ---- N = 2^16, fp64 policy: the one-pass inverse with the two TOP stages FIRST (k_ntt_inv_quad2, decimation in frequency on
+    // the natural-order input): a[4i'+c] = INTT'( psi^{-c(2k'+1)} sum_m A[k' + m N/4] I^{-cm} )[i'],  I = psi^{N/2},  INTT' the
+    // 2^14-point inverse over psi^4 (its tables are the first quarter of this limb's).  nullptr / 0 unless built (ntt_tables.h).
+    const ftwd_t* i2_t0;     // [3][2^LOGT]: psi^{-c(2t+1)} for c = 1, 2, 3 and t < 2^LOGT (the thread's first point; LOGT = 9)
+    double i2_g[3];          // psi^{-c 2^(LOGT+1)}: from point k' to k' + 2^LOGT
+    double i2_iinv;          // I^-1 = psi^{-N/2}
+    const ftwd_t* i2_winvb;  // boundary-permuted copy (LOGB = 14 geometry) of the first 2^14 entries of Winvd
 };
 
 // (ArithFpWide, the fp64 policy for digit lifts out of source limbs above 2^52, is defined after ArithFp below.)
@@ -123,6 +130,10 @@ struct lift_t {
     double c32, qim;  // 2^32 mod q_j and q_i mod q_j (ArithFpWide: lifts out of source limbs above 2^52; see lift_wide_consts)
 };
 TFHE_HD u64 lift_digit(u64 x, const lift_t& f) {
+    // |centred digit| <= q_i / 2: when that is below q_j (moduli of one size class, or a small limb lifted into a large one --
+    // uniform over the item) the lift is a conditional subtraction, no reduction; otherwise (a 60-bit limb into a 40-bit one,
+    // the unsigned lifts with q_i = 2^64 - 1) the 128-bit Barrett reduction
+    if (f.half < f.qj) return x > f.half ? f.qj - (f.qi - x) : x;
     return x > f.half ? negmod(barrett_reduce128(f.qi - x, 0, f.bj), f.qj) : barrett_reduce128(x, 0, f.bj);
 }
 
@@ -601,10 +612,15 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
 }
 template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCALE, int USEL = -1>
 TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename A::ctx& C, u32 tid,
-                       const u64* addend = nullptr) {
+                       const u64* addend = nullptr, u64* keep = nullptr) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
     constexpr bool TO_GLOBAL = (S0 == 0);
     if constexpr (TO_GLOBAL) {
+        if (keep) {  // the caller stores: element e = u * R + r belongs to word base(u) + (r << LO) (k_ntt_inv_quad2: 16-byte pieces)
+#pragma unroll
+            for (int i = 0; i < G::E; i++) keep[i] = SCALE ? A::out_inv_scaled(v[i], C) : A::out_inv_lazy(v[i], C);
+            return;
+        }
         // element e = u * R + r of this thread lives at word base(u) + (r << LO)
         u32 pos[G::SETS];
 #pragma unroll

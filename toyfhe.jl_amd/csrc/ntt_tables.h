@@ -27,6 +27,7 @@ inline void permute_boundary(const std::vector<T>& in, std::vector<T>& out, int 
 struct ntt_host_tabs_t {  // every table of one limb (host copies)
     std::vector<twd_t> W, Wi, Wb, Wib;
     std::vector<ftwd_t> Wd, Wid, Wdb, Widb;
+    std::vector<ftwd_t> I2t0, I2wib;  // N = 2^16, fp64 policy: k_ntt_inv_quad2 (ntt_limb_t::i2_*)
 };
 
 inline int build_ntt_tables(int64_t N, u64 q, u64 psi, std::vector<twd_t>& W, std::vector<twd_t>& Wi, ntt_limb_t* L,
@@ -66,6 +67,7 @@ inline int build_ntt_tables(int64_t N, u64 q, u64 psi, std::vector<twd_t>& W, st
     L->Wd = nullptr;
     L->Winvd = nullptr;
     L->Wb = nullptr; L->Winvb = nullptr; L->Wdb = nullptr; L->Winvdb = nullptr;
+    L->i2_t0 = nullptr; L->i2_winvb = nullptr; L->i2_iinv = 0.0; L->i2_g[0] = L->i2_g[1] = L->i2_g[2] = 0.0;
     if (q < TFHE_FP_QMAX && Wd && Wid) {
         Wd->resize((size_t)N);
         Wid->resize((size_t)N);
@@ -102,6 +104,29 @@ inline int build_ntt_tables_all(int64_t N, u64 q, u64 psi, ntt_host_tabs_t& T, n
                 L->Wdb = T.Wdb.data(); L->Winvdb = T.Widb.data();
             }
         }
+    }
+    if (logN == 16 && L->Wd) {
+        // k_ntt_inv_quad2 (kernels.h): the two top stages first, then four 2^14-point inverses over psi^4, whose tables are the
+        // first quarter of this limb's.  LOGB = 14, LOGT = 9 geometry.
+        using namespace hostmath;
+        constexpr int LB = 14, LT_ = logt_for(LB);
+        const u64 pinv = invmod_prime(psi, q);
+        T.I2t0.resize((size_t)3 << LT_);
+        for (int c = 1; c <= 3; c++) {
+            const u64 step = powmod(pinv, (u64)2 * c, q);               // psi^{-2c}: from point t to t + 1
+            u64 v = powmod(pinv, (u64)c, q);                             // psi^{-c (2t + 1)} at t = 0
+            for (u32 t = 0; t < (1u << LT_); t++) {
+                T.I2t0[((size_t)(c - 1) << LT_) + t] = (double)v;
+                v = mulmod_slow(v, step, q);
+            }
+            L->i2_g[c - 1] = (double)powmod(pinv, (u64)c << (LT_ + 1), q);   // psi^{-c 2^(LOGT+1)}: from point k' to k' + 2^LOGT
+        }
+        L->i2_iinv = (double)powmod(pinv, (u64)N / 2, q);
+        const int Kb = pass_k_inv(LB, LT_, LB);
+        std::vector<ftwd_t> first(T.Wid.begin(), T.Wid.begin() + ((size_t)1 << LB));
+        permute_boundary(first, T.I2wib, LB, Kb);
+        L->i2_t0 = T.I2t0.data();
+        L->i2_winvb = T.I2wib.data();
     }
     return 0;
 }

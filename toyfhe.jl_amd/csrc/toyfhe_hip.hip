@@ -386,6 +386,23 @@ int run_ntt_large(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t r
         return TFHE_OK;
     }
 #endif
+    // N = 2^16 inverse, out of place, in ONE pass (k_ntt_inv_quad2: the two top stages first, r04): 2 N 8 bytes per row instead of
+    // the 4 N 8 of the sub-block kernel + k_ntt_inv_top<2> below; TFHE_INV_I2=0 keeps the two-kernel path (comparisons)
+    static const bool inv_i2 = !(getenv("TFHE_INV_I2") && getenv("TFHE_INV_I2")[0] == '0');
+    if (inverse && pairable && x == 2 && !iop && src != dst && inv_i2) {
+        constexpr int LOGT = logt_for(14);
+        const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
+        auto qk = k_ntt_inv_quad2<ArithFp, 14, LOGT>;
+        static bool i2attr_set = false;
+        if (!i2attr_set) { int rc2 = set_lds(qk, lds); if (rc2) return rc2; i2attr_set = true; }
+        const unsigned items = (unsigned)(rows << 1);
+        const unsigned grid = std::min(items, (unsigned)c->num_cus);
+        prof_begin(c, rows);
+        hipLaunchKernelGGL(qk, dim3(grid), dim3(1 << LOGT), lds, c->stream, src, dst, c->limbs_dev, sel, items, io.limb_mask);
+        prof_end(c);
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
     void* tmp = nullptr;
     int rc = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
     if (rc) return rc;
@@ -640,7 +657,9 @@ int tfhe_ctx_create(int64_t N, int L, const uint64_t* q, const uint64_t* psi, tf
         bool ok = up(HT.W.data(), tb, (const void**)&LL.W) && up(HT.Wi.data(), tb, (const void**)&LL.Winv) &&
                   up(LL.Wb ? HT.Wb.data() : nullptr, tb, (const void**)&LL.Wb) && up(LL.Winvb ? HT.Wib.data() : nullptr, tb, (const void**)&LL.Winvb) &&
                   up(LL.Wd ? HT.Wd.data() : nullptr, fb, (const void**)&LL.Wd) && up(LL.Winvd ? HT.Wid.data() : nullptr, fb, (const void**)&LL.Winvd) &&
-                  up(LL.Wdb ? HT.Wdb.data() : nullptr, fb, (const void**)&LL.Wdb) && up(LL.Winvdb ? HT.Widb.data() : nullptr, fb, (const void**)&LL.Winvdb);
+                  up(LL.Wdb ? HT.Wdb.data() : nullptr, fb, (const void**)&LL.Wdb) && up(LL.Winvdb ? HT.Widb.data() : nullptr, fb, (const void**)&LL.Winvdb) &&
+                  up(LL.i2_t0 ? HT.I2t0.data() : nullptr, HT.I2t0.size() * sizeof(ftwd_t), (const void**)&LL.i2_t0) &&
+                  up(LL.i2_winvb ? HT.I2wib.data() : nullptr, HT.I2wib.size() * sizeof(ftwd_t), (const void**)&LL.i2_winvb);
         if (!ok) {
             tfhe_ctx_destroy(c);
             return fail(TFHE_E_HIP, "allocating the twiddle tables failed (no usable HIP device?)");
