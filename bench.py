@@ -283,7 +283,9 @@ def main():
     ctmul_bytes = 6 * L * N * 8
     traffic_per_ctmul = None
     if pmc and not pmc_stale:
-        traffic_per_ctmul = sum(v.get("hbm_bytes", 0.0) for v in pmc["kernels"].values()) / pmc["batch"]    # every kernel of the step
+        # every kernel of the step: per launch (a launch covers pmc["batch"] ciphertexts; the expansion runs twice per step)
+        per_launch = lambda k, v: v.get("hbm_bytes", 0.0) / max(1, v["launches"]) * (2 if "k_bfv_expand" in k else 1)
+        traffic_per_ctmul = sum(per_launch(k, v) for k, v in pmc["kernels"].items()) / pmc["batch"]
     roof = {
         "bound": "valu-fp64" if valu_frac is not None else "hbm",
         "kernel": "k_bfv_core_fused + k_ks_fused: the 2^14-point negacyclic NTTs (exact-integer fp64 butterflies) fused with the "

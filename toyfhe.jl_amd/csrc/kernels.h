@@ -2105,48 +2105,9 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 u64 op[E];  // first-pass operands of this sub-block (element bits)
                 // (the LDS-DMA streaming of dma_stream_load, which pays in k_ntt_fwd_quad, measured 7-9 % SLOWER here: cfg#3
                 // 32.6 k against 35.1 k key switches/s -- the piece-wise register loads below stay)
-#ifndef TFHE_KS_SUB_PIPE  // 1: the software-pipelined load phase below (X = 1); 0: the piece-wise loads of r01m (comparisons)
-#define TFHE_KS_SUB_PIPE 1
-#endif
-                if constexpr (X == 1 && TFHE_KS_SUB_PIPE) {
-                    // r04.  The piece-wise phase below exposes one L2 / Infinity-Cache round trip per piece: 4 x (16 requests, wait,
-                    // 8 lifts + top-stage products) per digit, 7 of the 28 us a digit takes (-DTFHE_ABL_NOROWS: + 13-18 % on the
-                    // key switch), because the compiler either hoists every request of the phase (spills next to the 128
-                    // accumulator registers) or, fenced, issues a piece only after the previous one has been consumed.  Here the
-                    // requests are inline asm with hand-counted waits (vmcnt is in order): pieces of 4 points (8 requests), three
-                    // pieces in flight while a fourth is being consumed -- 24 requests per thread under the arithmetic of a piece.
-                    // A requested register must not be touched before its wait: the waits take the piece's registers as "+v"
-                    // operands, and the kernel must stay free of spills (checked: scratch 0).
-                    constexpr int PE2 = 4, NP = E / PE2, SLOTS = 4;
-                    u64 q[SLOTS][2][PE2];
-                    const u32 off0 = tid << 3;
-                    auto issue = [&](int h) {
-#pragma unroll
-                        for (int r = 0; r < PE2; r++) {
-                            const u32 off = off0 + ((u32)(h * PE2 + r) << (LOGT + 3));
-                            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(q[h % SLOTS][0][r]) : "v"(off), "s"(grow) : "memory");
-                            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(q[h % SLOTS][1][r]) : "v"(off + (8u << LOGB)), "s"(grow) : "memory");
-                        }
-                    };
-                    issue(0); issue(1); issue(2);
-#pragma unroll
-                    for (int h = 0; h < NP; h++) {
-                        u64(&p)[2][PE2] = q[h % SLOTS];
-                        const int later = (NP - 1 - h) < 2 ? (NP - 1 - h) : 2;   // pieces requested after h and still in flight
-#define TFHE_WAIT_PIECE(n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(p[0][0]), "+v"(p[0][1]), "+v"(p[0][2]), "+v"(p[0][3]), "+v"(p[1][0]), "+v"(p[1][1]), "+v"(p[1][2]), "+v"(p[1][3]) : : "memory")
-                        if (later == 2) TFHE_WAIT_PIECE(16);
-                        else if (later == 1) TFHE_WAIT_PIECE(8);
-                        else TFHE_WAIT_PIECE(0);
-#undef TFHE_WAIT_PIECE
-                        if (h + 3 < NP) issue(h + 3);
-#pragma unroll
-                        for (int r = 0; r < PE2; r++) {
-                            const double lo = A::from_global_lift(p[0][r], C, lf, true), hv = A::from_global_lift(p[1][r], C, lf, true);
-                            const double z = fp_fma(sgn_h, fp_mulmod_c(hv, w1, C.p, C.pinv), lo);
-                            op[h * PE2 + r] = A::to_lds(fp_reduce(z, C.p, C.pinv));
-                        }
-                    }
-                } else {
+                // (r04: the same phase software-pipelined by hand -- inline-asm requests, pieces of 4 points, 24 requests in flight under
+                // the arithmetic of a piece, hand-counted vmcnt waits; bit-exact, scratch unchanged -- measured 7 % SLOWER: 34.1 k against
+                // 36.6 k key switches/s at cfg#3, although a build without the row loads gains 13 %.  profiles/LOG.md.)
                 constexpr int PC = 4 * X, PE = E / PC;  // pieces of the load phase (bounds the raw words in flight)
 #pragma unroll
                 for (int h = 0; h < PC; h++) {
@@ -2183,7 +2144,6 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                         op[h * PE + r] = A::to_lds(fp_reduce(z, C.p, C.pinv));
                     }
                     TFHE_SCHED_FENCE();
-                }
                 }
                 if (!first) __syncthreads();  // the previous transform's last pass has read LDS
                 first = false;

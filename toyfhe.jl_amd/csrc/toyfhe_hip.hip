@@ -2,6 +2,7 @@
 // gfx950 only.  No torch types, no oracle code, no CPU fallback: every compute entry point launches
 // HIP kernels and fails with TFHE_E_HIP if the device is unavailable.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cstdarg>
@@ -62,7 +63,7 @@ struct tfhe_ctx {
     // workspace (grown on demand, reused)
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    bool ws_pooled = false;   // the block came from the recycling allocator (large per-call workspaces, ws_giveback)
+    bool ws_pooled = false;   // the block came from the recycling allocator (large per-call workspaces, ws_borrow_t)
     // profiling
     bool prof = false;
     std::vector<prof_pair> prof_pairs;
@@ -80,7 +81,7 @@ struct tfhe_ctx {
 
 namespace {
 
-// pooled: the block is taken from (and, by ws_giveback, returned to) the recycling allocator instead of being owned by the
+// pooled: the block is taken from (and, by ws_borrow_t, returned to) the recycling allocator instead of being owned by the
 // context for its lifetime -- for the large per-call workspaces (tfhe_matmul_diag: tens of GiB).  A parked block is reused by
 // the next call of the same shape without a synchronisation, counts against the allocator's cache bound, and is given back to
 // the driver by tfhe_alloc_trim and by every out-of-memory retry of the library (devalloc::malloc_retry).
@@ -105,18 +106,26 @@ int ensure_ws(tfhe_ctx* c, size_t bytes, void** out, bool pooled = false) {
     *out = c->ws;
     return TFHE_OK;
 }
-// a pooled workspace goes back to the allocator when the call that sized it returns
-void ws_giveback(tfhe_ctx* c) {
-    if (c->ws && c->ws_pooled) {
-        (void)devalloc::release(c->ws);
-        c->ws = nullptr;
-        c->ws_bytes = 0;
-        c->ws_pooled = false;
-    }
-}
-struct ws_guard_t {
+// A pooled workspace lives for ONE call: the context's own (long-lived, small) workspace is set aside while the call runs --
+// the transforms inside it take their scratch from c->ws -- and comes back untouched when the call returns; the pooled block
+// goes back to the allocator.  (First form, r04: the pooled block REPLACED the context's workspace; every large call then cost
+// the next small operation a hipMalloc and itself a stream synchronisation + hipFree of that small block: the encrypted-MNIST
+// pass went from 78 to 145 ms.)
+struct ws_borrow_t {
     tfhe_ctx* c;
-    ~ws_guard_t() { ws_giveback(c); }
+    void* ws = nullptr;
+    size_t bytes = 0;
+    bool pooled = false, active = false;
+    explicit ws_borrow_t(tfhe_ctx* ctx) : c(ctx) {}
+    void begin() {
+        ws = c->ws; bytes = c->ws_bytes; pooled = c->ws_pooled; active = true;
+        c->ws = nullptr; c->ws_bytes = 0; c->ws_pooled = false;
+    }
+    ~ws_borrow_t() {
+        if (!active) return;
+        if (c->ws) { if (c->ws_pooled) (void)devalloc::release(c->ws); else { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ws); } }
+        c->ws = ws; c->ws_bytes = bytes; c->ws_pooled = pooled;
+    }
 };
 // workspaces above this size are per-call (pooled); TFHE_WS_KEEP_GIB overrides
 size_t ws_keep_bytes() {
@@ -1644,23 +1653,37 @@ int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
     // already hold, both of which the allocation below can reuse): other contexts, BFV plans and processes keep their room
     size_t ws_cap = ws_cap_env;
     {
+        // (hipMemGetInfo is a driver round trip -- milliseconds in a process with many allocations -- and this call sits in the
+        // launch path of a host-bound circuit: the reading is kept for two seconds)
+        static std::mutex mi_mu;
+        static size_t mi_free = 0;
+        static std::chrono::steady_clock::time_point mi_at{};
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        bool have = false;
+        {
+            std::lock_guard<std::mutex> g(mi_mu);
+            const auto now = std::chrono::steady_clock::now();
+            if (mi_free && now - mi_at < std::chrono::seconds(2)) { fr = mi_free; have = true; }
+            else if (hipMemGetInfo(&fr, &tot) == hipSuccess) { mi_free = fr; mi_at = now; have = true; }
+            else (void)hipGetLastError();
+        }
+        if (have) {
             uint64_t cached = 0;
             tfhe_alloc_stats(nullptr, &cached, nullptr, nullptr);
             ws_cap = std::min(ws_cap, std::max<size_t>((fr + c->ws_bytes + (size_t)cached) / 2, (size_t)1 << 30));
-        } else (void)hipGetLastError();
+        }
     }
     int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)(ws_cap / per_ct)}));
     size_t ntt_tmp = 0;
     void* ws = nullptr;
     int rc;
-    ws_guard_t ws_guard{c};   // a workspace above ws_keep_bytes() is this call's: back to the allocator on every return path
-    for (;;) {
+    ws_borrow_t borrow(c);    // a workspace above ws_keep_bytes() is this call's: back to the allocator on every return path
+    for (bool first_try = true;; first_try = false) {
         const size_t ntt_rows = (size_t)chunk * std::max<size_t>({(size_t)level * nw, (size_t)R * 2 * nw, (size_t)2 * level});
         ntt_tmp = c->logN > 14 ? ntt_rows * N * 8 : 0;
         const size_t need = ntt_tmp + chunk * per_ct;
-        rc = ensure_ws(c, need, &ws, need > ws_keep_bytes());
+        if (first_try && need > ws_keep_bytes() && need > c->ws_bytes) borrow.begin();
+        rc = ensure_ws(c, need, &ws, borrow.active);
         if (rc != TFHE_E_NOMEM || chunk == 1) break;
         chunk = (chunk + 1) / 2;
     }
