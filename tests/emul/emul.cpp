@@ -55,13 +55,16 @@ void block_inv_a(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
 }
 // fp64 butterflies when the modulus qualifies and the caller did not force the u64 path (mirrors sel_fp in toyfhe_hip.hip)
 static bool g_force_int = false;
+static bool g_small = false;   // variant 3: the range plan of the size class below 2^42 (ArithFpS)
 template <int LOGB>
 void block_fwd(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
-    if (L.Wd && !g_force_int) block_fwd_a<ArithFp, LOGB>(src, dst, L, x); else block_fwd_a<ArithInt, LOGB>(src, dst, L, x);
+    if (L.Wd && g_small) block_fwd_a<ArithFpS, LOGB>(src, dst, L, x);
+    else if (L.Wd && !g_force_int) block_fwd_a<ArithFp, LOGB>(src, dst, L, x); else block_fwd_a<ArithInt, LOGB>(src, dst, L, x);
 }
 template <int LOGB>
 void block_inv(const u64* src, u64* dst, const ntt_limb_t& L, int x) {
-    if (L.Wd && !g_force_int) block_inv_a<ArithFp, LOGB>(src, dst, L, x); else block_inv_a<ArithInt, LOGB>(src, dst, L, x);
+    if (L.Wd && g_small) block_inv_a<ArithFpS, LOGB>(src, dst, L, x);
+    else if (L.Wd && !g_force_int) block_inv_a<ArithFp, LOGB>(src, dst, L, x); else block_inv_a<ArithInt, LOGB>(src, dst, L, x);
 }
 
 template <int X>
@@ -80,7 +83,8 @@ void top_inv(const u64* src, u64* dst, const ntt_limb_t& L, int logn) {
 extern "C" {
 
 // one limb-polynomial transform; variant 0 = register-blocked path (logn >= 10; fp64 butterflies when the
-// modulus qualifies), 1 = generic radix-2, 2 = register-blocked path with u64 butterflies forced.
+// modulus qualifies), 1 = generic radix-2, 2 = register-blocked path with u64 butterflies forced, 3 = register-blocked path
+// with the fp64 range plan of moduli below 2^42 (ArithFpS).
 // returns 0, -1 on bad psi, -2 on unsupported size
 int emul_ntt(int logn, uint64_t q, uint64_t psi, int inverse, int variant, const uint64_t* src, uint64_t* dst) {
     const int64_t N = 1ll << logn;
@@ -89,6 +93,8 @@ int emul_ntt(int logn, uint64_t q, uint64_t psi, int inverse, int variant, const
     ntt_limb_t L;
     if (build_ntt_tables_all(N, q, psi, HT, &L)) return -1;
     g_force_int = (variant == 2);
+    g_small = (variant == 3);
+    if (g_small && q >= TFHE_FPS_QMAX) return -2;
     if (variant == 1 || logn < 10) {
         if (logn > 14) return -2;
         std::vector<u64> lds((size_t)N);

@@ -60,6 +60,30 @@ def test_fp64_butterflies_at_the_modulus_limit_and_worst_case_inputs(logn):
     assert 0 < worst < 2.0**53 / q, worst
 
 
+@pytest.mark.parametrize("logn", [10, 13, 14, 15, 16])
+def test_fp64_small_modulus_range_plan_at_its_limit(logn):
+    """ArithFpS (fp64arith.h, r04): moduli below 2^42 run without forward sweeps and with one sweep per inverse.  At the largest
+    NTT-friendly prime below 2^42, on growth-maximising inputs, the block passes give the oracle's words and every operand of a
+    modular product / reduction stays below 2^53 (2048 p there; the plan's own limit is 2000)."""
+    N = 1 << logn
+    q = ((2**42) // (2 * N)) * (2 * N) + 1
+    while q >= 2**42 or not spec.is_prime(q):
+        q -= 2 * N
+    assert q > 2**42 - 2**30
+    ctx = ref_cpu.RefCtx(N, [q])
+    pats = [np.full(N, q - 1, dtype=np.uint64), np.array([0, q - 1] * (N // 2), dtype=np.uint64),
+            np.full(N, (q - 1) // 2, dtype=np.uint64), np.random.default_rng(logn).integers(0, q, size=N, dtype=np.uint64)]
+    emul.fp_max_ratio_reset()
+    for a in pats:
+        want = ctx.nntt(a.reshape(1, 1, N)).reshape(N)
+        assert np.array_equal(emul.ntt(a, q, variant=3), want)
+        assert np.array_equal(emul.ntt(want, q, inverse=True, variant=3), a)
+        wi = ctx.inntt(a.reshape(1, 1, N)).reshape(N)
+        assert np.array_equal(emul.ntt(a, q, inverse=True, variant=3), wi)
+    worst = emul.fp_max_ratio_reset()
+    assert 1.0 < worst < 2000.0, worst          # it does use the room (no sweeps) and stays inside the plan's limit
+
+
 @pytest.mark.parametrize("logn", [15, 16])
 def test_ntt_bodies_large_n(logn):
     N = 1 << logn

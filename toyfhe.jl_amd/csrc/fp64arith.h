@@ -29,6 +29,14 @@
 #define TFHE_FP_LIMIT 7.9           /* < 2^53 / TFHE_FP_QMAX = 7.992 */
 #endif
 
+// A second size class (r04): moduli below 2^42 -- the 40-bit chains of the reference's CKKS parameter sets (test/ckks_*.jl,
+// infer.jl:98-107).  a = p 2^-52 < 2^-10, so a stage adds 1/2 + 0.0015 b and the exactness limit is 2^53 / p > 2048: a forward
+// transform of any supported size needs NO sweep (1 + 17 x 0.52 < 10), key-product terms need no reduced operand, and an inverse
+// transform (sums double per stage) needs one sweep per ~11 stages instead of one per pass (ArithFpS, ntt_core.h).
+#define TFHE_FPS_QMAX (1ull << 42)
+#define TFHE_FPS_A 0.000977         /* >= 2^42 2^-52 */
+#define TFHE_FPS_LIMIT 2000.0       /* < 2^53 / 2^42 = 2048 */
+
 struct ftw_t {  // twiddle w, an exact integer < p
     double w;
 };

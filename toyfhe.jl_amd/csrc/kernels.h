@@ -2015,7 +2015,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 #endif
                     // range: y reduced to |y| <= p/2, so every term is <= (1/2 + 0.75 a) p = 0.69 p and eight of them stay
                     // below the 7.9 p exactness limit (fp64arith.h); the accumulators are swept every eighth digit
-                    const double y = fp_reduce(v[e], C.p, C.pinv);
+                    const double y = A::pre_product(v[e], C);
                     acc[0][e] += fp_mulmod_c(y, k1, C.p, C.pinv);
                     acc[1][e] += fp_mulmod_c(y, k0, C.p, C.pinv);
                 }
@@ -2141,7 +2141,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                             const double yb = fp_fma(sgn_h, fp_mulmod_c(xin[3], w1, C.p, C.pinv), xin[1]);
                             z = fp_fma(sgn_q, fp_mulmod_c(yb, w2, C.p, C.pinv), ya);
                         }
-                        op[h * PE + r] = A::to_lds(fp_reduce(z, C.p, C.pinv));
+                        op[h * PE + r] = A::to_lds(A::top_reduce(z, C));
                     }
                     TFHE_SCHED_FENCE();
                 }
@@ -2170,7 +2170,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
                     const int e = u * G3::R + r;
                     const typename A::tw k1{A::from_lds(e_masked[nat << X])}, k0{A::from_lds(e_mask[nat << X])};
-                    const double y = fp_reduce(v[e], C.p, C.pinv);  // range: as k_ks_fused
+                    const double y = A::pre_product(v[e], C);  // range: as k_ks_fused
                     acc[0][e] += fp_mulmod_c(y, k1, C.p, C.pinv);
                     acc[1][e] += fp_mulmod_c(y, k0, C.p, C.pinv);
                 }

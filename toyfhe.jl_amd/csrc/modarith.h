@@ -48,7 +48,32 @@ TFHE_HD void mul64_full(u64 a, u64 b, u64& lo, u64& hi) {
 }
 
 // x * w mod q for a precomputed (w, wp); x is ANY u64, result in [0, 2q)  (Harvey/Shoup lazy form)
-TFHE_HD u64 shoup_lazy(u64 x, tw_t t, u64 q) { return x * t.w - mulhi64(x, t.wp) * q; }
+// Device form (r04): r = lo64(x w + qh (2^64 - q)) accumulated by v_mad_u64_u32 on a running 64-bit sum -- the low products of
+// x w and of qh q share one accumulator, so there is no 64-bit subtraction (v_sub_co / v_subb and the wait state between them)
+// and four multiplier instructions carry their additions for free: 30 instructions per butterfly where the plain expression
+// below compiled to 33.5 (hipcc -S of eight chained butterflies; profiles/LOG.md r04).  Same value: everything is mod 2^64.
+TFHE_HD u64 shoup_lazy(u64 x, tw_t t, u64 q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), p0 = (u32)t.wp, p1 = (u32)(t.wp >> 32);
+    const u64 m = (u64)x1 * p0 + __umulhi(x0, p0);
+    const u64 n = (u64)x0 * p1 + (u32)m;
+    const u64 qh = (u64)x1 * p1 + (m >> 32) + (n >> 32);                     // mulhi64(x, wp)
+    const u64 nq = 0 - q;
+    const u32 w0 = (u32)t.w, w1 = (u32)(t.w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32), h0 = (u32)qh, h1 = (u32)(qh >> 32);
+    u64 r = (u64)x0 * w0;
+    r = (u64)h0 * n0 + r;
+    const u32 hi = (u32)(r >> 32) + x0 * w1 + x1 * w0 + h0 * n1 + h1 * n0;
+    return ((u64)hi << 32) | (u32)r;
+#else
+    return x * t.w - mulhi64(x, t.wp) * q;
+#endif
+}
+// conditional subtraction for the butterflies' ranges (x < 2 m <= 2^63 + ..: x - m < 2^63 whenever x >= m, and wraps above 2^63
+// otherwise): the sign of the difference selects -- one 64-bit add of the constant -m instead of a compare and a borrow chain
+TFHE_HD u64 csub_s(u64 x, u64 m) {
+    const u64 d = x + (0 - m);
+    return (long long)d < 0 ? x : d;
+}
 // same, fully reduced to [0, q)
 TFHE_HD u64 shoup_full(u64 x, tw_t t, u64 q) {
     u64 r = shoup_lazy(x, t, q);

@@ -72,13 +72,13 @@ constexpr int pass_k_inv(int logb, int logt, int s_end) { return (s_end % (logb 
 
 // Harvey butterflies.  Forward keeps values in [0,4q); inverse keeps them in [0,2q).
 TFHE_HD void bfly_fwd(u64& x, u64& y, tw_t w, u64 q) {
-    u64 u = csub(x, 2 * q);
+    u64 u = csub_s(x, 2 * q);    // x < 4q < 2^64, 2q < 2^63
     u64 t = shoup_lazy(y, w, q);
     x = u + t;
-    y = u - t + 2 * q;
+    y = u + 2 * q - t;
 }
 TFHE_HD void bfly_inv(u64& x, u64& y, tw_t w, u64 q) {
-    u64 a = csub(x + y, 2 * q);
+    u64 a = csub_s(x + y, 2 * q);  // x + y < 4q
     u64 d = x + 2 * q - y;
     x = a;
     y = shoup_lazy(d, w, q);
@@ -171,6 +171,9 @@ struct ArithInt {
         y = shoup_lazy(d, c.w1n, c.q);
     }
     static constexpr bool fwd_sweep_before(int, int) { return false; }  // Harvey butterflies keep [0, 4q) by themselves
+    static constexpr double fp_a = TFHE_FP_A, fp_lim = TFHE_FP_LIMIT;   // (range plans: unused, range_inv is a no-op)
+    template <int LOGB, int LOGT, int S0> static constexpr bool inv_lds_reduce() { return false; }
+    template <int LOGB, int LOGT, int SEND> static constexpr double inv_entry() { return 0.502; }
     static TFHE_HD void range_fwd(elem&, const ctx&) {}
     static TFHE_HD void range_inv(elem&, const ctx&) {}
     static TFHE_HD u64 out_fwd(elem v, const ctx& c) { return csub(csub(v, 2 * c.q), c.q); }
@@ -197,6 +200,10 @@ struct ArithFp {
     static constexpr bool prefetch_tw = true;
     static constexpr bool moddown = false;   // ArithFpMD: the final store is the ModulusRaised contraction (inv_store)
     static constexpr bool fwd_sweep_before(int nstages, int s) { return fp_fwd_sweep_before(nstages, s); }
+    // inverse range plan: every value stored to LDS is reduced (|v| <= p/2 at the start of every pass); ArithFpS relaxes this
+    static constexpr double fp_a = TFHE_FP_A, fp_lim = TFHE_FP_LIMIT;
+    template <int LOGB, int LOGT, int S0> static constexpr bool inv_lds_reduce() { return true; }
+    template <int LOGB, int LOGT, int SEND> static constexpr double inv_entry() { return 0.502; }
     typedef double elem;
     typedef ftw_t tw;
     struct ctx {
@@ -270,6 +277,9 @@ struct ArithFp {
     }
     static TFHE_HD void range_fwd(elem& v, const ctx& c) { v = fp_reduce(v, c.p, c.pinv); }
     static TFHE_HD void range_inv(elem& v, const ctx& c) { v = fp_reduce(v, c.p, c.pinv); }
+    // operand of a key / tensor product, output of a top stage formed at load: reduced (ArithFpS: left as they are)
+    static TFHE_HD elem pre_product(elem v, const ctx& c) { return fp_reduce(v, c.p, c.pinv); }
+    static TFHE_HD elem top_reduce(elem v, const ctx& c) { return fp_reduce(v, c.p, c.pinv); }
     static TFHE_HD u64 out_fwd(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
     static TFHE_HD u64 out_inv_scaled(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
     static TFHE_HD u64 out_inv_lazy(elem v, const ctx& c) { return fp_canon(v, c.p, c.pinv); }
@@ -330,6 +340,48 @@ TFHE_HD void lift_wide_consts<ArithFpWide>(lift_t& f) {
     f.c32 = (double)barrett_reduce128(1ull << 32, 0, f.bj);
     f.qim = (double)barrett_reduce128(f.qi, 0, f.bj);
 }
+
+// ---- ArithFpS: the fp64 policy for moduli below 2^42 (fp64arith.h) -------------------------------------------------------------
+// Bounds in units of p.  Forward: no sweep at all.  Inverse (Gentleman-Sande: a sum doubles the bound, a product returns to
+// 1/2 + 0.0015 b): walking the passes from the first (entry <= 0.502: centred residues / reduced sums), a pass of K stages leaves
+// <= 2^K b + K; the values are reduced at a pass's LDS store only when the NEXT pass would otherwise pass the limit.  For the
+// 2^14-point geometry (passes of 4 / 5 / 5 stages): 0.502 -> 8.1 (stored as it is) -> 262 (reduced at the store) -> 0.502 -> 17.
+constexpr double fps_inv_growth(double b, int K) {
+    for (int k = 0; k < K; k++) b = 2.0 * b + 1.0;
+    return b;
+}
+constexpr bool fps_inv_reduce(int logb, int logt, int s0) {
+    double b = 0.502;
+    for (int S = logb; S > 0;) {
+        const int K = pass_k_inv(logb, logt, S), S0 = S - K;
+        const double out = fps_inv_growth(b, K);
+        const bool red = S0 > 0 && fps_inv_growth(out, pass_k_inv(logb, logt, S0)) > TFHE_FPS_LIMIT;
+        if (S0 == s0) return red;
+        b = red ? 0.502 : out;
+        S = S0;
+    }
+    return true;
+}
+constexpr double fps_inv_entry(int logb, int logt, int send) {
+    double b = 0.502;
+    for (int S = logb; S > 0;) {
+        if (S == send) return b;
+        const int K = pass_k_inv(logb, logt, S), S0 = S - K;
+        const double out = fps_inv_growth(b, K);
+        const bool red = S0 > 0 && fps_inv_growth(out, pass_k_inv(logb, logt, S0)) > TFHE_FPS_LIMIT;
+        b = red ? 0.502 : out;
+        S = S0;
+    }
+    return b;
+}
+struct ArithFpS : ArithFp {
+    static constexpr bool fwd_sweep_before(int, int) { return false; }
+    static constexpr double fp_a = TFHE_FPS_A, fp_lim = TFHE_FPS_LIMIT;
+    template <int LOGB, int LOGT, int S0> static constexpr bool inv_lds_reduce() { return fps_inv_reduce(LOGB, LOGT, S0); }
+    template <int LOGB, int LOGT, int SEND> static constexpr double inv_entry() { return fps_inv_entry(LOGB, LOGT, SEND); }
+    static TFHE_HD elem pre_product(elem v, const ctx&) { return v; }   // <= 10 p after a forward transform: terms <= 0.52 p
+    static TFHE_HD elem top_reduce(elem v, const ctx&) { return v; }    // <= 3 p into the first forward pass
+};
 
 // Optional transforms fused into the block kernels' global I/O (key switching, src/rlwe_she.jl:326-344):
 //   lift_t  : forward first pass reads limb i of a polynomial and lifts it, centred, into limb j --
@@ -540,9 +592,8 @@ struct inv_plan_t {
     u32 mask[8];
 };
 template <int K>
-constexpr inv_plan_t make_inv_plan() {
+constexpr inv_plan_t make_inv_plan(double a = TFHE_FP_A, double lim = TFHE_FP_LIMIT, double b0 = 0.502) {
     inv_plan_t P{};
-    constexpr double a = TFHE_FP_A, lim = TFHE_FP_LIMIT, b0 = 0.502;
     double b[1 << K] = {};
     for (int i = 0; i < (1 << K); i++) b[i] = b0;
     for (int st = 0; st < K; st++) {
@@ -552,7 +603,7 @@ constexpr inv_plan_t make_inv_plan() {
                 const int r0 = (g << (K - d)) + i, r1 = r0 + half;
                 while (b[r0] + b[r1] > lim) {
                     const int m = b[r0] >= b[r1] ? r0 : r1;
-                    b[m] = b0;
+                    b[m] = 0.502;
                     P.mask[st] |= 1u << m;
                 }
                 const double sm = b[r0] + b[r1];
@@ -584,7 +635,7 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
         for (int d = K - 1; d >= 0; d--) {
             const int half = 1 << (K - 1 - d);
             {
-                constexpr inv_plan_t PLAN = make_inv_plan<K>();
+                constexpr inv_plan_t PLAN = make_inv_plan<K>(A::fp_a, A::fp_lim, A::template inv_entry<LOGB, LOGT, S0 + K>());
 #pragma unroll
                 for (int r = 0; r < G::R; r++)
                     if ((PLAN.mask[K - 1 - d] >> r) & 1u) A::range_inv(vv[r], C);
@@ -693,7 +744,7 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
 #pragma unroll
             for (int r = 0; r < G::R; r++) {
                 typename A::elem e = v[u * G::R + r];
-                A::range_inv(e, C);
+                if (A::template inv_lds_reduce<LOGB, LOGT, S0>()) A::range_inv(e, C);
                 lds[lds_phi<LOGB, LOGT>(base) + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)] = A::to_lds(e);
             }
         }

@@ -1410,9 +1410,19 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         constexpr int LOGT = logt_for(14);
         const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
         const int x = 1;
-        auto fk = k_ks_fused_sub<ArithFp, 14, LOGT, 1>;
+        // moduli below 2^42 (the 40-bit chains of the reference's CKKS rings): the range plan of that size class -- no forward
+        // sweeps, no reduced product operands, one sweep per inverse (ArithFpS): cfg#3 36.5 k -> 38.1 k key switches/s
+        bool small = true;
+        for (int j = 0; j < nw; j++) small = small && c->q[A.w.idx[j]] < TFHE_FPS_QMAX;
+        static const bool fps_on = !(getenv("TFHE_FPS") && getenv("TFHE_FPS")[0] == '0');
+        auto fk = (small && fps_on) ? k_ks_fused_sub<ArithFpS, 14, LOGT, 1> : k_ks_fused_sub<ArithFp, 14, LOGT, 1>;
         static bool sattr_set = false;
-        if (!sattr_set) { rc = set_lds(fk, lds); if (rc) return rc; sattr_set = true; }
+        if (!sattr_set) {
+            rc = set_lds(k_ks_fused_sub<ArithFp, 14, LOGT, 1>, lds);
+            if (!rc) rc = set_lds(k_ks_fused_sub<ArithFpS, 14, LOGT, 1>, lds);
+            if (rc) return rc;
+            sattr_set = true;
+        }
         const unsigned items = (unsigned)((batch * nw) << x);
         const unsigned grid = std::min(items, (unsigned)c->num_cus);
         prof_begin(c, (int64_t)batch * nw * (level + 2));
