@@ -99,7 +99,9 @@ struct ntt_limb_t {   // per-limb constants (device copy lives in the context)
     // copies of the tables permuted for the boundary pass (forward last / inverse first pass), whose thread->group
     // map is bit-reversed: entry (2^s + (c0 << d) + g) of the copy = entry (2^s + (brv(c0) << d) + g) of the
     // table, so that the lanes of a wavefront read consecutive entries instead of 64 different cache lines.
-    // Valid for whole-transform blocks (x == 0) of the geometry they were built for; nullptr otherwise.
+    // Built for the geometry of the ring's degree: whole-transform blocks (N <= 2^14: pre = 1), and since r04 the 2^14-point
+    // sub-blocks of larger transforms -- every sub-block prefix pre = 2^x + sb owns the index range [pre << s, (pre + 1) << s) of
+    // stage block s and is permuted within it (ntt_tables.h permute_boundary_sub); nullptr when not built.
     const twd_t* Wb;
     const twd_t* Winvb;
     const ftwd_t* Wdb;
@@ -445,8 +447,8 @@ TFHE_HD void fwd_load_tw(typename A::tw* tw, const typename A::ctx& C, u32 tid, 
         for (int d = D0; d < D1; d++)
 #pragma unroll
             for (int g = 0; g < (1 << d); g++)
-                tw[u * G::NTW + (1 << d) - 1 + g] = (LAST && pre == 1u && A::has_b(C))
-                                                        ? A::ld_fwd_b(C, (1u << (S0 + d)) + (c0 << d) + (u32)g)
+                tw[u * G::NTW + (1 << d) - 1 + g] = (LAST && A::has_b(C))
+                                                        ? A::ld_fwd_b(C, (pre << (S0 + d)) + (c0 << d) + (u32)g)
                                                         : A::ld_fwd(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
     }
 }
@@ -475,7 +477,7 @@ template <class A, int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int
 TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
                          u32 pre, const lift_t* lift = nullptr, const HOOK& hook = HOOK()) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
-    const bool use_b = LAST && pre == 1u && A::has_b(C);  // permuted boundary table of whole-transform blocks
+    const bool use_b = LAST && A::has_b(C);  // permuted boundary table (whole transforms, and since r04 the sub-blocks of larger ones)
     if (FIRST && lift) {  // digit lift: all conversions first, then the butterflies (register pressure)
 #pragma unroll
         for (int i = 0; i < G::E; i++) v[i] = A::from_global_lift(raw[i], C, *lift, true);
@@ -621,7 +623,7 @@ template <class A, int LOGB, int LOGT, int S0, int K, bool FROM_GLOBAL, bool SCA
 TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::tw* twp, const typename A::ctx& C, u32 tid,
                          u32 pre, const HOOK& hook = HOOK()) {
     typedef pgeom<LOGB, LOGT, S0, K> G;
-    const bool use_b = FROM_GLOBAL && pre == 1u && A::has_b(C);
+    const bool use_b = FROM_GLOBAL && A::has_b(C);
 #pragma unroll
     for (int u = 0; u < G::SETS; u++) {
         if (USEL >= 0 && u != USEL) continue;
@@ -647,7 +649,7 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
                     for (int i = 0; i < half; i++) A::bf_inv_scaled(vv[i], vv[i + half], C);
                 } else {
                     const typename A::tw w = d >= K - PF ? twp[u * G::NTW + (1 << d) - 1 + g]
-                                             : (FROM_GLOBAL && use_b) ? A::ld_inv_b(C, (1u << (S0 + d)) + (c0 << d) + (u32)g)
+                                             : (FROM_GLOBAL && use_b) ? A::ld_inv_b(C, (pre << (S0 + d)) + (c0 << d) + (u32)g)
                                                                       : A::ld_inv(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
 #pragma unroll
                     for (int i = 0; i < half; i++) {

@@ -24,6 +24,26 @@ inline void permute_boundary(const std::vector<T>& in, std::vector<T>& out, int 
     }
 }
 
+// the same for the 2^logb-point sub-blocks of a 2^(logb+x)-point transform: local stage hb + d of sub-block prefix pre (2^x <= pre <
+// 2^(x+1)) reads entries (pre << (hb + d)) + (hi << d) + g; the permuted copy holds them at (pre << (hb + d)) + (c0 << d) + g with
+// hi = brv_hb(c0).  Before r04 the boundary passes of every N > 2^14 kernel loaded their twiddles through the bit-reversed index:
+// 64 different cache lines per wave-load (k_ntt_fwd_quad fetched 1.6 x its algorithmic bytes, the one-pass inverse with a permuted
+// table 1.1 x).
+template <class T>
+inline void permute_boundary_sub(const std::vector<T>& in, std::vector<T>& out, int logb, int x, int Kb) {
+    out = in;
+    const int hb = logb - Kb;
+    for (u32 pre = 1u << x; pre < (2u << x); pre++)
+        for (int d = 0; d < Kb; d++) {
+            const size_t base = (size_t)pre << (hb + d);
+            for (u32 c0 = 0; c0 < (1u << hb); c0++) {
+                u32 r = 0;
+                for (int b = 0; b < hb; b++) r |= ((c0 >> b) & 1u) << (hb - 1 - b);
+                for (u32 g = 0; g < (1u << d); g++) out[base + ((size_t)c0 << d) + g] = in[base + ((size_t)r << d) + g];
+            }
+        }
+}
+
 struct ntt_host_tabs_t {  // every table of one limb (host copies)
     std::vector<twd_t> W, Wi, Wb, Wib;
     std::vector<ftwd_t> Wd, Wid, Wdb, Widb;
@@ -101,6 +121,23 @@ inline int build_ntt_tables_all(int64_t N, u64 q, u64 psi, ntt_host_tabs_t& T, n
             if (L->Wd) {
                 permute_boundary(T.Wd, T.Wdb, logN, Kb);
                 permute_boundary(T.Wid, T.Widb, logN, Kb);
+                L->Wdb = T.Wdb.data(); L->Winvdb = T.Widb.data();
+            }
+        }
+    }
+    if (logN > 14 && logN <= 17) {
+        // N > 2^14: 2^14-point sub-blocks (LOGB = 14 geometry) behind / in front of x = logN - 14 top stages
+        constexpr int LB = 14;
+        const int x = logN - LB, logt = logt_for(LB);
+        int s0 = 0, Kb = 0;
+        while (s0 < LB) { Kb = pass_k_fwd(LB, logt, s0); s0 += Kb; }
+        if (Kb == pass_k_inv(LB, logt, LB)) {
+            permute_boundary_sub(T.W, T.Wb, LB, x, Kb);
+            permute_boundary_sub(T.Wi, T.Wib, LB, x, Kb);
+            L->Wb = T.Wb.data(); L->Winvb = T.Wib.data();
+            if (L->Wd) {
+                permute_boundary_sub(T.Wd, T.Wdb, LB, x, Kb);
+                permute_boundary_sub(T.Wid, T.Widb, LB, x, Kb);
                 L->Wdb = T.Wdb.data(); L->Winvdb = T.Widb.data();
             }
         }
