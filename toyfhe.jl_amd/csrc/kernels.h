@@ -1765,7 +1765,7 @@ __device__ __forceinline__ void fused_fwd_to_regs(u64* lds, const u64* grow, con
 // butterfly instead of two scaling products per pair
 template <class A, int LOGB, int LOGT, bool SCALE = true, bool TWL = false, class AO = A>
 __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* v, u64* gdst, const typename A::ctx& C, const u64* addend,
-                                                    u64* keep = nullptr) {
+                                                    u64* keep = nullptr, u32 pre = 1u) {   // pre: sub-block prefix (2^x + sb) of a larger transform
     constexpr int KI1 = pass_k_inv(LOGB, LOGT, LOGB);
     constexpr int E = 1 << (LOGB - LOGT);
     const u32 tid = fresh_tid();
@@ -1790,12 +1790,12 @@ __device__ __forceinline__ void fused_inv_from_regs(u64* lds, typename A::elem* 
         {
 #pragma unroll
             for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], C.p, C.pinv);
-            inv_compute<A, LOGB, LOGT, S1, KI1, true, SCALE, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, 1u);
-            if constexpr (S1 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S1 - K2, K2, false>(tw_next, C, tid, 1u);
+            inv_compute<A, LOGB, LOGT, S1, KI1, true, SCALE, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, pre);
+            if constexpr (S1 - K2 != 0) inv_load_tw<A, LOGB, LOGT, S1 - K2, K2, false>(tw_next, C, tid, pre);
             inv_store<A, LOGB, LOGT, S1, KI1, true, SCALE>(v, lds, nullptr, C, tid);
         }
         __syncthreads();
-        inv_schedule_ptw<A, LOGB, LOGT, S1, SCALE, AO>(lds, nullptr, gdst, C, tid, 1u, addend, tw_next, keep);
+        inv_schedule_ptw<A, LOGB, LOGT, S1, SCALE, AO>(lds, nullptr, gdst, C, tid, pre, addend, tw_next, keep);
     }
 }
 
@@ -2186,18 +2186,9 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
         // the sub-block's inverse passes on the two accumulators (first pass from registers: same natural-order map)
 #pragma unroll
         for (int sidx = 0; sidx < 2; sidx++) {
-            const u32 tid = fresh_tid();
             u64* gdst = T + ((size_t)((b * 2 + sidx) * nw + j) << (LOGB + X)) + ((size_t)sb << LOGB);
-            __syncthreads();  // the previous transform's last pass has read LDS
-            {
-                typename A::elem* v = acc[sidx];
-#pragma unroll
-                for (int e = 0; e < E; e++) v[e] = fp_reduce(v[e], C.p, C.pinv);
-                inv_compute<A, LOGB, LOGT, S1, KI1, true, false, 0, -1, no_hook, true>(v, nullptr, nullptr, C, tid, pre);
-                inv_store<A, LOGB, LOGT, S1, KI1, true, false>(v, lds, nullptr, C, tid);
-            }
-            __syncthreads();
-            inv_schedule<A, LOGB, LOGT, S1, false>(lds, nullptr, gdst, C, tid, pre, 0, 0u, nullptr);
+            // (r04: the middle pass's twiddles requested before the exchange, as in k_ks_fused)
+            fused_inv_from_regs<A, LOGB, LOGT, false, false, A>(lds, acc[sidx], gdst, C, nullptr, nullptr, pre);
         }
     }
 }
