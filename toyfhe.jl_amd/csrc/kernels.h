@@ -1519,7 +1519,23 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
     const u32 per = (batch + bsplit - 1) / bsplit, b_lo = slice * per, b_hi = b_lo + per < batch ? b_lo + per : batch;
     if (k >= n) return;
     const ntt_limb_t L = LT[A.w.idx[j]];
-    const int lazy = L.br.sh <= 50 ? (1 << 10) : (L.br.sh <= 58 ? (1 << (60 - L.br.sh)) : 1);
+    // Lazy sums of full products, one reduction per `lazy` terms.  Moduli up to 52 bits: the 128-bit sum goes straight into the
+    // Barrett reduction (z < 2^(sh+64)).  Wider moduli (r04; the 60-bit q0 / special prime of the reference's CKKS rings used to
+    // be reduced after EVERY term, 2 x level Barrett reductions per coefficient -- the kernel ran at 0.9 VALU issue): the high
+    // word is folded first, z' = hi (2^64 mod q) + lo < 2^(sh+64) for up to 2^(126 - 2 bits) - 1 terms (15 at 61 bits, 3 at 62),
+    // then ONE Barrett reduction -- the same canonical residue.
+    const u32 qbits = L.br.sh + 2;
+    const bool fold = qbits > 52;
+    const int lazy = fold ? (qbits <= 61 ? DCH : 3) : (1 << 10);
+    static_assert(DCH <= 15, "fold budget at 61 bits");
+    const u64 c64 = fold ? barrett_reduce128(0, 1, L.br) : 0;   // 2^64 mod q
+    auto reduce = [&](const acc128& s) -> u64 {
+        if (!fold) return barrett_reduce128(s.lo, s.hi, L.br);
+        u64 lo, hi;
+        mul64_full(s.hi, c64, lo, hi);
+        const u64 l2 = lo + s.lo;
+        return barrett_reduce128(l2, hi + (l2 < lo), L.br);
+    };
     for (int i0 = 0; i0 < A.level; i0 += DCH) {
         u64 mk[DCH], md[DCH];
 #pragma unroll
@@ -1551,15 +1567,15 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
                         acc_mac(s1, md[ii], d[h][ii]);
                         acc_mac(s2, mk[ii], d[h][ii]);
                         if (++pend == lazy) {
-                            r1[h] = addmod(r1[h], barrett_reduce128(s1.lo, s1.hi, L.br), L.q);
-                            r2[h] = addmod(r2[h], barrett_reduce128(s2.lo, s2.hi, L.br), L.q);
+                            r1[h] = addmod(r1[h], reduce(s1), L.q);
+                            r2[h] = addmod(r2[h], reduce(s2), L.q);
                             s1 = acc128{0, 0}; s2 = acc128{0, 0}; pend = 0;
                         }
                     }
                 }
                 if (pend) {
-                    r1[h] = addmod(r1[h], barrett_reduce128(s1.lo, s1.hi, L.br), L.q);
-                    r2[h] = addmod(r2[h], barrett_reduce128(s2.lo, s2.hi, L.br), L.q);
+                    r1[h] = addmod(r1[h], reduce(s1), L.q);
+                    r2[h] = addmod(r2[h], reduce(s2), L.q);
                 }
                 if constexpr (EPI) {
                     if (i0 + DCH >= A.level && j < (u32)A.level) {
