@@ -102,6 +102,20 @@ def encrypted_matmul(gk, W, x, B, cache=None, fused=False):
     return result
 
 
+def add_bias(ct, x, cache=None, name=None):
+    """ct .+ bias (infer.jl: the `.+ b` of every layer).  With a cache the bias is encoded once per (layer, level, scale) like the
+    weight plaintexts -- each encoding is a host-to-device copy the pass would otherwise wait on -- and added to the first
+    component as CipherText.add_plain does."""
+    if cache is None:
+        return ct.add_plain(x)
+    key = ("bias", name, ct.ring().L, ct.scale)
+    if key not in cache:
+        n2 = ct.ring().N // 2
+        v = np.full(n2, x, dtype=np.complex128) if np.isscalar(x) else np.asarray(x, dtype=np.complex128)
+        cache[key] = tf.ckks_encode(v, ct.ring(), ct.scale)
+    return tf.CipherText(ct.params, (ct.cs[0] + cache[key],) + tuple(ct.cs[1:]), ct.scale)
+
+
 GOLDEN_MODEL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "mnist_conv.npz")
 
 
@@ -173,7 +187,7 @@ def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=Fal
                   for j in range(7):
                       term = C[i][j].mul_plain(float(model["conv_w"][i, j, ch]))
                       acc = term if acc is None else acc + term
-          conved.append(tf.modswitch(acc.add_plain(float(model["conv_b"][ch]))))
+          conved.append(tf.modswitch(add_bias(acc, float(model["conv_b"][ch]), cache, ("conv", ch))))
       if fused:    # the four channels' squares, relinearisations and rescales as ONE batch of 4 K ciphertexts
           big = tf.CipherText.concat(conved)
           sq1 = tf.modswitch(tf.keyswitch(ek, big * big)).split([K] * 4)
@@ -183,9 +197,9 @@ def run(logn=13, seed=0, verbose=True, model="reference", batches=1, hoisted=Fal
       for i in range(4):
           part = encrypted_matmul(gk, fq1_blocks[i], sq1[i], B, cache, fused)
           fq1 = part if fq1 is None else fq1 + part
-      fq1 = tf.modswitch(fq1.add_plain(np.repeat(model["fq1_b"], B)))
+      fq1 = tf.modswitch(add_bias(fq1, np.repeat(model["fq1_b"], B), cache, "fq1"))
       sq2 = tf.modswitch(tf.keyswitch(ek, fq1 * fq1))
-      res = encrypted_matmul(gk, W2, sq2, B, cache, fused).add_plain(np.repeat(np.concatenate([model["fq2_b"], np.zeros(54)]), B))
+      res = add_bias(encrypted_matmul(gk, W2, sq2, B, cache, fused), np.repeat(np.concatenate([model["fq2_b"], np.zeros(54)]), B), cache, "fq2")
       ev1.record(res[0].ring.ctx)
       t_enq = time.perf_counter() - t0                                # every launch of the circuit is enqueued; the device may still be running
       dec = tf.ckks_decode(tf.decrypt(kp, res), res.scale).real       # [K][N/2]

@@ -293,7 +293,8 @@ def test_golden_modswitch_galois():
 # ---------------------------------------------------------------------------------------------------
 # K9-K11: keyswitch / rotate
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,bits,Lk", [(32, 40, 4), (2048, 50, 3), (8192, 50, 4), (16384, 50, 4), (1 << 15, 50, 3), (1 << 16, 50, 3)])
+@pytest.mark.parametrize("N,bits,Lk", [(32, 40, 4), (2048, 50, 3), (8192, 50, 4), (16384, 50, 4), (1 << 15, 50, 3), (1 << 16, 50, 3),
+                                       (1 << 15, 40, 4), (1 << 16, 40, 4)])
 @pytest.mark.parametrize("special", [True, False])
 def test_keyswitch_matches_oracle(N, bits, Lk, special):
     qs = H.chain(bits, Lk, N)
@@ -317,6 +318,30 @@ def test_keyswitch_matches_oracle(N, bits, Lk, special):
         ctx.keyswitch(Lk, 1, special, devk.ptr, Lk, devk.ptr, 4, devk.ptr, 1)      # rlwe_she.jl:318
     with pytest.raises(tf.UsageError):
         ctx.keyswitch(Lk, Lk + 1, special, devk.ptr, Lk, devk.ptr, 2, devk.ptr, 1)  # level outside the key ring
+
+
+@pytest.mark.parametrize("bits", [50, 40])
+def test_keyswitch_sub_block_fused_at_2_16_more_items_than_workgroups(bits):
+    """k_ks_fused_sub at X = 2 (four sub-blocks per row, quarters streamed through the LDS) with several items per workgroup:
+    44 ciphertexts x 3 working limbs x 4 sub-blocks = 528 items on 256 workgroups; fp64 policy (50 bit) and the small-modulus
+    range plan (40 bit).  Picks against the oracle, every ciphertext against the three-kernel path's bits (single-ciphertext
+    calls go the same fused way, so the cross-check is the batch permuted)."""
+    N, Lk, level, batch = 1 << 16, 3, 2, 44
+    qs = H.chain(bits, Lk, N)
+    ref = ref_cpu.RefCtx(N, qs); ctx = tf.Context(N, qs)
+    rng = np.random.default_rng(bits)
+    evk = H.uniform_evk(rng, qs, Lk, N)
+    devk = dev(evk)
+    ct = H.rand_residues(rng, qs[:level], (batch, 2), N)
+    dct, dout = dev(ct), tf.DeviceBuffer(batch * 2 * level * N)
+    ctx.keyswitch(Lk, level, True, devk.ptr, Lk, dct.ptr, 2, dout.ptr, batch)
+    got = dout.to_numpy((batch, 2, level, N))
+    pick = [0, 21, batch - 1]
+    assert np.array_equal(got[pick], ref.keyswitch(level, True, evk, ct[pick]))
+    perm = rng.permutation(batch)
+    dct2, dout2 = dev(ct[perm]), tf.DeviceBuffer(batch * 2 * level * N)
+    ctx.keyswitch(Lk, level, True, devk.ptr, Lk, dct2.ptr, 2, dout2.ptr, batch)
+    assert np.array_equal(dout2.to_numpy((batch, 2, level, N)), got[perm])
 
 
 @pytest.mark.parametrize("N,bits,Lk,level,batch", [(8192, 40, 6, 3, 300), (16384, 50, 5, 4, 270)])

@@ -2082,6 +2082,13 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 // The digit rows and their transforms never reach HBM; the sub-block items of a (b, j) run on one XCD (xcd_walk_item)
 // and share the source rows in its L2.
 // ------------------------------------------------------------------------------------------------
+// load phase of k_ks_fused_sub: LDS-DMA streaming (dma_stream_load) at X = 2, piece-wise register loads at X = 1 (measured)
+#ifndef TFHE_FSUB_DMA2
+#define TFHE_FSUB_DMA2 1
+#endif
+#ifndef TFHE_FSUB_DMA1
+#define TFHE_FSUB_DMA1 0
+#endif
 template <class A, int LOGB, int LOGT, int X>
 __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restrict__ evd, const u64* __restrict__ ct,
                                                              u64* __restrict__ T, const ntt_limb_t* __restrict__ LT,
@@ -2125,6 +2132,24 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 // the arithmetic of a piece, hand-counted vmcnt waits; bit-exact, scratch unchanged -- measured 7 % SLOWER: 34.1 k against
                 // 36.6 k key switches/s at cfg#3, although a build without the row loads gains 13 %.  profiles/LOG.md.)
                 constexpr int PC = 4 * X, PE = E / PC;  // pieces of the load phase (bounds the raw words in flight)
+                if constexpr (X == 2 ? TFHE_FSUB_DMA2 : TFHE_FSUB_DMA1) {
+                    // the 2^X parts: streamed through the LDS as in k_ntt_fwd_quad (the LDS holds no row image here)
+                    if (!first) __syncthreads();  // the previous transform's last pass has read LDS
+                    dma_stream_load<LOGB, LOGT, 1 << X, 2>(lds, grow, tid, [&](int e, const u64* q) {
+                        double xin[1 << X];
+#pragma unroll
+                        for (int m = 0; m < (1 << X); m++) xin[m] = A::from_global_lift(q[m], C, lf, true);
+                        double z;
+                        if constexpr (X == 1) {
+                            z = fp_fma(sgn_h, fp_mulmod_c(xin[1], w1, C.p, C.pinv), xin[0]);
+                        } else {
+                            const double ya = fp_fma(sgn_h, fp_mulmod_c(xin[2], w1, C.p, C.pinv), xin[0]);
+                            const double yb = fp_fma(sgn_h, fp_mulmod_c(xin[3], w1, C.p, C.pinv), xin[1]);
+                            z = fp_fma(sgn_q, fp_mulmod_c(yb, w2, C.p, C.pinv), ya);
+                        }
+                        op[e] = A::to_lds(A::top_reduce(z, C));
+                    });
+                } else
 #pragma unroll
                 for (int h = 0; h < PC; h++) {
                     u64 q[1 << X][PE];
@@ -2161,9 +2186,11 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                     }
                     TFHE_SCHED_FENCE();
                 }
-                if (!first) __syncthreads();  // the previous transform's last pass has read LDS
+                constexpr bool DMA = X == 2 ? TFHE_FSUB_DMA2 : TFHE_FSUB_DMA1;
+                if (!DMA && !first) __syncthreads();  // the previous transform's last pass has read LDS
                 first = false;
                 fwd_compute<A, LOGB, LOGT, 0, K1, false, false, 0>(v, op, nullptr, C, tid, pre);
+                if (DMA) __syncthreads();  // every wave has read its ring
                 fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
             }
             __syncthreads();

@@ -1057,6 +1057,10 @@ static bool ks_fused14(const tfhe_ctx* c, int Lk, int level, int special) {
         static const bool on = !(getenv("TFHE_FUSED13") && getenv("TFHE_FUSED13")[0] == '0');
         return on && sel_fp(c, w, 0);
     }
+    if (c->logN == 16) {  // k_ks_fused_sub at X = 2
+        static const bool on16 = !(getenv("TFHE_FUSED16") && getenv("TFHE_FUSED16")[0] == '0');
+        return on16 && level >= 2 && sel_fp(c, w, 2);
+    }
     return c->logN == 15 && level >= 2 && sel_fp(c, w, 1);  // k_ks_fused_sub
 }
 // pre-lifted c[end] rows (centred doubles from the BFV contraction) are understood by k_ks_fused only
@@ -1403,23 +1407,29 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
-    if (evd && c->logN == 15) {  // ks_fused14: variant 0, fp64 policy, level >= 2
-        // N = 2^15: per-sub-block fused key switch (k_ks_fused_sub) into T = dig ([batch][2][nw] rows, level >= 2 makes
-        // room), then the inverse top stage over T and the usual tail.  (The X = 2 instance for N = 2^16 measured slower
-        // than the three-kernel path below: 235 spilled registers next to the 128 accumulator registers.)
+    if (evd && (c->logN == 15 || c->logN == 16)) {  // ks_fused14: variant 0, fp64 policy, level >= 2
+        // N = 2^15 / 2^16 on fp64-size moduli: per-sub-block fused key switch (k_ks_fused_sub) into T = dig ([batch][2][nw] rows,
+        // level >= 2 makes room), then the inverse top stages over T together with the tail.  At 2^16 (X = 2) the four quarters
+        // of a digit row stream through the LDS (dma_stream_load, no spills: 33.0 k against 32.1 k key switches/s for the
+        // three-kernel path on 7 x 50 bit; with register loads the X = 2 load phase either spilled 237 registers or ran as 32
+        // serial rounds: 26-28 k).  At 2^15 the register loads stay (the streamed form measured 36.2 k against 40.2 k, cfg#3).
+        // TFHE_FUSED16=0 keeps the three-kernel path at 2^16.
         constexpr int LOGT = logt_for(14);
         const size_t lds = (size_t)lds_words<14, LOGT>() * 8;
-        const int x = 1;
+        const int x = c->logN - 14;
         // moduli below 2^42 (the 40-bit chains of the reference's CKKS rings): the range plan of that size class -- no forward
         // sweeps, no reduced product operands, one sweep per inverse (ArithFpS): cfg#3 36.5 k -> 38.1 k key switches/s
         bool small = true;
         for (int j = 0; j < nw; j++) small = small && c->q[A.w.idx[j]] < TFHE_FPS_QMAX;
         static const bool fps_on = !(getenv("TFHE_FPS") && getenv("TFHE_FPS")[0] == '0');
-        auto fk = (small && fps_on) ? k_ks_fused_sub<ArithFpS, 14, LOGT, 1> : k_ks_fused_sub<ArithFp, 14, LOGT, 1>;
+        auto fk = x == 2 ? ((small && fps_on) ? k_ks_fused_sub<ArithFpS, 14, LOGT, 2> : k_ks_fused_sub<ArithFp, 14, LOGT, 2>)
+                         : ((small && fps_on) ? k_ks_fused_sub<ArithFpS, 14, LOGT, 1> : k_ks_fused_sub<ArithFp, 14, LOGT, 1>);
         static bool sattr_set = false;
         if (!sattr_set) {
             rc = set_lds(k_ks_fused_sub<ArithFp, 14, LOGT, 1>, lds);
             if (!rc) rc = set_lds(k_ks_fused_sub<ArithFpS, 14, LOGT, 1>, lds);
+            if (!rc) rc = set_lds(k_ks_fused_sub<ArithFp, 14, LOGT, 2>, lds);
+            if (!rc) rc = set_lds(k_ks_fused_sub<ArithFpS, 14, LOGT, 2>, lds);
             if (rc) return rc;
             sattr_set = true;
         }
@@ -1436,7 +1446,8 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
             const u64 P = c->q[Lk - 1];
             for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
         }
-        hipLaunchKernelGGL(k_ks_top_tail<1>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 2), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
+        if (x == 1) hipLaunchKernelGGL(k_ks_top_tail<1>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 2), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
+        else hipLaunchKernelGGL(k_ks_top_tail<2>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 4), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
