@@ -77,6 +77,28 @@ def test_bfv_crt():
         c * tf.CipherText(other, c.cs)
 
 
+def test_bfv_products_against_the_plaintext_ring():
+    """test/bfv_crt.jl:39-47 with the plaintext written the reference's way -- an element of plaintext_space(params), the
+    psi = 0 ring whose products are the naive negacyclic convolution (pow2_cyc_rings.jl:150-165) -- and whole-polynomial
+    plaintexts: Dec(c1 * c2) == p1 * p2 and Dec(c1 + c2) == p1 + p2 in Z_53[x]/(x^N + 1)."""
+    n = 1024
+    ch = chain(2**50 + 1, 6, n)
+    R, Rbig = tf.NegacyclicRing(n, ch[:2]), tf.NegacyclicRing(n, ch[2:])
+    params = tf.BFVParams(R, Rbig, 53, 0, 3.2)
+    P = params.plaintext_space()
+    assert isinstance(P, tf.PlainRing) and P.modulus() == 53
+    rng = np.random.default_rng(7)
+    kp = tf.keygen(rng, params)
+    plain = P.zero()
+    plain[0] = 6
+    c = tf.encrypt(rng, kp, plain)
+    assert tf.decrypt(kp, c * c)[0] == (plain * plain)[0] == 0x24
+    p1, p2 = P(rng.integers(0, 53, n)), P(rng.integers(0, 53, n))
+    c1, c2 = tf.encrypt(rng, kp, p1), tf.encrypt(rng, kp, p2)
+    assert (p1 * p2) == tf.decrypt(kp, c1 * c2)
+    assert (p1 + p2) == tf.decrypt(kp, c1 + c2)
+
+
 def test_bfv_enc_mul_any_component_counts():
     """enc_mul as rlwe_she.jl:247-262 writes it -- any numbers of components: (c*c)*c without relinearisation (3 x 2 -> 4
     components), bit for bit against the oracle's switch -> convolution over ℛbig -> multround/switch, and decrypted with

@@ -7,7 +7,7 @@ The directory name contains a dot, so import it through the repo-root loader mod
 from . import native  # noqa: F401
 from .native import BfvPlan, Comm, Context, DeviceBuffer, Event, HipError, UsageError  # noqa: F401
 from . import ring, she  # noqa: F401,E402
-from .ring import NegacyclicRing, RingElement, nextprime  # noqa: F401,E402
+from .ring import NegacyclicRing, PlainElement, PlainRing, RingElement, nextprime, plaintext_space  # noqa: F401,E402
 from . import wire  # noqa: F401,E402
 from .she import (DeviceRng, BFVParams, BGVParams, CKKSParams, CipherText, ModulusRaised, apply_galois_element,  # noqa: F401,E402
                   ckks_decode, ckks_encode, decrypt, enc_mul, encrypt, invariant_noise_budget, keygen, keygen_evalmult, keygen_galois,

@@ -4,7 +4,9 @@ This is the Python stand-in for the Julia shim (``julia/ToyFHEHIP.jl``; no Julia
 build image): same names, argument meaning and error behaviour as ``src/pow2_cyc_rings.jl`` and the RNS
 hooks of ``src/crt.jl``, with every polynomial held in device memory and every operation executed by
 libtoyfhe_hip.so through the C ABI.  Nothing here computes on the CPU except the per-coefficient
-``getindex``/``setindex!`` conveniences and host<->device conversion, which download/upload.
+``getindex``/``setindex!`` conveniences and host<->device conversion, which download/upload -- and ``PlainRing``, the
+reference's psi = 0 plaintext rings (naive convolution, "just for plaintexts and testing", pow2_cyc_rings.jl:150-165), which
+have no transform and stay on the host by design.
 
 A ``RingElement`` may carry a leading batch dimension (a batch of independent ring elements sharing one
 ring): that is how batches of ciphertexts reach the batched kernels.
@@ -406,3 +408,129 @@ class RingElement:
 def zero(x):
     """Base.zero(r::RingElement) / zero(ℛ), pow2_cyc_rings.jl:83-85,121-122."""
     return x.ring.zero(x.batch) if isinstance(x, RingElement) else x.zero()
+
+
+# --------------------------------------------------------------------------------------------------
+# psi = 0 rings: NegacyclicRing{coefft, N}() (pow2_cyc_rings.jl:39-41) -- the plaintext spaces of BFV / BGV whose modulus has no
+# 2N-th root of unity (plaintext_space, rlwe_she.jl:380-392).  The reference multiplies them by the naive negacyclic convolution
+# (pow2_cyc_rings.jl:150-165, "just for plaintexts and testing"); so does this mirror, on the host: there is nothing to accelerate.
+# --------------------------------------------------------------------------------------------------
+class PlainRing:
+    """Z_t[x]/(x^N + 1) without a root of unity (psi = 0).  ``ring(coeffs)`` / ``ring.zero()`` make elements."""
+
+    def __init__(self, N: int, t: int):
+        if N < 1 or N & (N - 1):
+            raise AssertionError("degree must be a power of two")          # pow2_cyc_rings.jl:29
+        if t < 2:
+            raise AssertionError("plaintext modulus must be at least 2")
+        self.N, self.t = int(N), int(t)
+
+    psi = 0
+
+    def degree(self):
+        return self.N
+
+    def modulus(self) -> int:
+        return self.t
+
+    def __eq__(self, o):
+        return isinstance(o, PlainRing) and (self.N, self.t) == (o.N, o.t)
+
+    def __hash__(self):
+        return hash((self.N, self.t, 0))
+
+    def __repr__(self):
+        return f"ℤ_{self.t}/(x^{self.N} + 1)"
+
+    def __call__(self, coeffs) -> "PlainElement":
+        return PlainElement(self, coeffs)
+
+    def zero(self) -> "PlainElement":
+        return PlainElement(self, [0] * self.N)
+
+
+class PlainElement:
+    """RingElement of a psi = 0 ring: primal coefficients only (Python integers mod t), 0-based like the reference's OffsetArray."""
+
+    def __init__(self, ring: PlainRing, coeffs):
+        coeffs = list(coeffs)
+        if len(coeffs) > ring.N:
+            raise AssertionError("more coefficients than the degree")
+        self.ring = ring
+        self.c = [int(x) % ring.t for x in coeffs] + [0] * (ring.N - len(coeffs))
+
+    def __len__(self):
+        return self.ring.N
+
+    def __iter__(self):
+        return iter(self.c)
+
+    def __getitem__(self, i):
+        return self.c[i]
+
+    def __setitem__(self, i, v):
+        self.c[i] = int(v) % self.ring.t
+
+    def to_ints(self):
+        return list(self.c)
+
+    def _same(self, o):
+        if not isinstance(o, PlainElement) or o.ring != self.ring:
+            raise UsageError("operands belong to different rings")
+
+    def __eq__(self, o):
+        if isinstance(o, PlainElement):
+            return self.ring == o.ring and self.c == o.c
+        try:
+            o = list(o)
+        except TypeError:
+            return NotImplemented
+        return len(o) == self.ring.N and all(int(a) % self.ring.t == b for a, b in zip(o, self.c))
+
+    __hash__ = None
+
+    def __add__(self, o):
+        self._same(o)
+        return PlainElement(self.ring, [a + b for a, b in zip(self.c, o.c)])
+
+    def __sub__(self, o):
+        self._same(o)
+        return PlainElement(self.ring, [a - b for a, b in zip(self.c, o.c)])
+
+    def __neg__(self):
+        return PlainElement(self.ring, [-a for a in self.c])
+
+    def __mul__(self, o):
+        if isinstance(o, (int, np.integer)):                                   # scalar_mul, pow2_cyc_rings.jl:177-180
+            return PlainElement(self.ring, [int(o) * a for a in self.c])
+        self._same(o)
+        N, t = self.ring.N, self.ring.t
+        # naive negacyclic convolution (pow2_cyc_rings.jl:150-165): res[i+j] += a_i b_j, wrapped with a sign change past x^N
+        if N * t * t < 2 ** 62:
+            full = np.convolve(np.array(self.c, dtype=np.int64), np.array(o.c, dtype=np.int64))
+        else:
+            full = np.convolve(np.array(self.c, dtype=object), np.array(o.c, dtype=object))
+        res = [int(x) for x in full[:N]]
+        for k in range(N, 2 * N - 1):
+            res[k - N] -= int(full[k])
+        return PlainElement(self.ring, res)
+
+    __rmul__ = __mul__
+
+    def __pow__(self, e: int):                                                 # Base.:^ by repeated multiplication (:182-186)
+        if e < 1:
+            raise UsageError("positive powers only")
+        r = self
+        for _ in range(e - 1):
+            r = r * self
+        return r
+
+
+def plaintext_space(ring, t: int):
+    """plaintext_space(ℛ, p), rlwe_she.jl:380-392: a prime p > 2N gets the ring with its minimal 2N-th root (device storage, NTT
+    products -- what SlotEncoding needs); anything else the psi = 0 ring.  (The reference leaves the existence of the root as a
+    TODO and fails in minimal_primitive_root when it does not exist; here such a prime falls back to psi = 0.)"""
+    N = ring.N if hasattr(ring, "N") else int(ring)
+    if isprime(t) and t > 2 * N and (t - 1) % (2 * N) == 0:
+        return NegacyclicRing(N, [t])
+    return PlainRing(N, t)

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import native
 from .native import BfvPlan, DeviceBuffer, UsageError
-from .ring import NegacyclicRing, RingElement
+from .ring import NegacyclicRing, RingElement, plaintext_space as _plaintext_space
 
 DOT_MAX = 64   # operands / rotations one device pass of tfhe_dot, tfhe_lincomb[_many], tfhe_matmul_diag takes (TFHE_DOT_MAX, csrc/kernels.h)
 
@@ -151,6 +151,10 @@ class BFVParams(SHESchemeParams):
         self.plan().contract(e.coeffs_primal().ptr, out.ptr, n)
         return RingElement(self.ring, out, None, e.batch)
 
+    def plaintext_space(self):
+        """ℛ_plain (bfv.jl:18, rlwe_she.jl:380-392): the psi = 0 host ring unless t is a prime with a 2N-th root."""
+        return _plaintext_space(self.ring, self.t)
+
     def encode(self, plain) -> RingElement:
         """π⁻¹, bfv.jl:21-24: Δ * plaintext (a list of coefficients, or a list of such lists = a batch)."""
         return self.ring(_map_plain(plain, lambda m: self.delta * (int(m) % self.t)))
@@ -180,6 +184,10 @@ class BGVParams(SHESchemeParams):
 
     def noise(self, rng, ring, batch=None):  # ShiftedDiscreteNormal, bgv.jl:27-34
         return sample_noise(rng, ring, self.sigma, batch, self.t)
+
+    def plaintext_space(self):
+        """ℛ_plain (bgv.jl:18)."""
+        return _plaintext_space(self.ring, self.t)
 
     def encode(self, plain):
         return self.ring(_map_plain(plain, lambda m: int(m) % self.t))
