@@ -1498,8 +1498,8 @@ struct ks_arg_t {
 // (rlwe_she.jl:340-344).  One thread owns coefficient k of limb j for the WHOLE chunk of ciphertexts, so the
 // evaluation-key values are loaded once into registers and reused across the batch (the key is shared by
 // all ciphertexts; re-reading it per ciphertext was the dominant traffic).  grid = nw * ceil(N/256).
-// several keys against the same digits in one launch (the rotations of a diagonal product, tfhe_matmul_diag): blockIdx.y
-// selects the key and the slice of S it writes; n == 0: the single key `evk`
+// several keys against the same digits in one launch (the rotations of a diagonal product, tfhe_matmul_diag): the workgroup's
+// position selects the key and the slice of S it writes (ks_multi_key_block); n == 0: the single key `evk`
 struct ks_keys_t {
     int n;
     size_t s_stride;  // words of S per key
@@ -1507,13 +1507,29 @@ struct ks_keys_t {
                       // leaves as V = S P^-1 (+ X[b][0][j] for s = 0) instead of S (k_md_v folded into the store)
     const u64* key[TFHE_DOT_MAX];
 };
+// Several keys in one launch: a 1-D grid in which the workgroups of ONE (limb, tile, batch slice) for all the keys sit next to
+// each other on ONE XCD (workgroup b runs on XCD b & 7): they stream the same digit words at the same time, so the digit rows
+// are fetched from HBM once per launch instead of once per key (the keys and the sums are per key anyway).
+// Returns false for the padding workgroups of the last group of eight.
+__device__ __forceinline__ bool ks_multi_key_block(const ks_keys_t& K, u32 nx, u32& bx, u32& key) {
+    const u32 bid = blockIdx.x, q = bid >> 3;
+    key = q % (u32)K.n;
+    bx = (q / (u32)K.n) * 8u + (bid & 7u);
+    return bx < nx;
+}
 template <int DCH, bool EPI = false>
 __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, const u64* __restrict__ dig,
                                                    u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
                                                    int Lk, u32 n, u32 batch, u32 bsplit, u32 limb_mask, ks_keys_t K) {
-    if (K.n) { evk = K.key[blockIdx.y]; S += (size_t)blockIdx.y * K.s_stride; }
-    // blockIdx.x = (slice * nw + j) * gx + tile; slice = which part of the batch this workgroup owns
-    const u32 gx = (n + 255) / 256, tile = blockIdx.x % gx, j = (blockIdx.x / gx) % (u32)A.nw, slice = blockIdx.x / (gx * (u32)A.nw);
+    // bx = (slice * nw + j) * gx + tile; slice = which part of the batch this workgroup owns
+    const u32 gx = (n + 255) / 256;
+    u32 bx = blockIdx.x;
+    if (K.n) {
+        u32 key;
+        if (!ks_multi_key_block(K, gx * (u32)A.nw * bsplit, bx, key)) return;
+        evk = K.key[key]; S += (size_t)key * K.s_stride;
+    }
+    const u32 tile = bx % gx, j = (bx / gx) % (u32)A.nw, slice = bx / (gx * (u32)A.nw);
     if (limb_mask && !((limb_mask >> j) & 1u)) return;  // rings of mixed modulus sizes: the narrow kernel takes the other limbs
     const u32 k = tile * 256 + threadIdx.x;
     const u32 per = (batch + bsplit - 1) / bsplit, b_lo = slice * per, b_hi = b_lo + per < batch ? b_lo + per : batch;
@@ -1601,9 +1617,15 @@ template <int DCH, bool EPI = false>
 __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk, const u64* __restrict__ dig,
                                                       u64* __restrict__ S, const ntt_limb_t* __restrict__ LT, ks_arg_t A,
                                                       int Lk, u32 n, u32 batch, u32 bsplit, u32 limb_mask, ks_keys_t K) {
-    if (K.n) { evk = K.key[blockIdx.y]; S += (size_t)blockIdx.y * K.s_stride; }
     static_assert(DCH + 1 <= 16, "acc52 term budget");
-    const u32 gx = (n / 2 + 255) / 256, tile = blockIdx.x % gx, j = (blockIdx.x / gx) % (u32)A.nw, slice = blockIdx.x / (gx * (u32)A.nw);
+    const u32 gx = (n / 2 + 255) / 256;
+    u32 bx = blockIdx.x;
+    if (K.n) {
+        u32 key;
+        if (!ks_multi_key_block(K, gx * (u32)A.nw * bsplit, bx, key)) return;
+        evk = K.key[key]; S += (size_t)key * K.s_stride;
+    }
+    const u32 tile = bx % gx, j = (bx / gx) % (u32)A.nw, slice = bx / (gx * (u32)A.nw);
     if (limb_mask && !((limb_mask >> j) & 1u)) return;
     const u32 k = (tile * 256 + threadIdx.x) * 2;
     const u32 per = (batch + bsplit - 1) / bsplit, b_lo = slice * per, b_hi = b_lo + per < batch ? b_lo + per : batch;

@@ -1206,6 +1206,8 @@ static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* ev
     const unsigned bsplit = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx * gy - 1) / (nw * gx * gy)));
     // working limbs below 2^52: the two-coefficient, carry-free kernel; the others: the generic one (more than 32 working
     // limbs: all or nothing, see mask_of)
+    // several keys: groups of eight x-blocks (one per XCD), each followed by its keys (ks_multi_key_block)
+    auto multi = [&](unsigned nx) { return keys ? dim3(((nx + 7u) / 8u) * 8u * gy) : dim3(nx); };
     u32 nmask = mask_of(nw, [&](int j) { return (c->limbs_host[A.w.idx[j]].q >> 52) == 0; });
     const u32 amask = mask_all(nw);
     if (n % 2 != 0) nmask = 0;
@@ -1213,12 +1215,12 @@ static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* ev
         const unsigned gx2 = (n / 2 + 255) / 256;
         const unsigned bs2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx2 * gy - 1) / (nw * gx2 * gy)));
         auto kn = epi_x ? k_ks_inner_n2<8, true> : k_ks_inner_n2<8, false>;
-        hipLaunchKernelGGL(kn, dim3((unsigned)nw * gx2 * bs2, gy), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2,
+        hipLaunchKernelGGL(kn, multi((unsigned)nw * gx2 * bs2), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bs2,
                            nmask == amask ? 0u : nmask, K);
     }
     if (nmask != amask) {
         auto kg = epi_x ? k_ks_inner<8, true> : k_ks_inner<8, false>;
-        hipLaunchKernelGGL(kg, dim3((unsigned)nw * gx * bsplit, gy), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit,
+        hipLaunchKernelGGL(kg, multi((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit,
                            nmask ? (amask & ~nmask) : 0u, K);
     }
     HIP_TRY(hipGetLastError());
