@@ -1963,7 +1963,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_quad2(const u64* __restri
 // fused kernel's inner product, where every word is used once per ciphertext of the batch.
 // fold_ninv: the words are multiplied by N^-1 mod q_j on the way (k_ks_fused runs its inverse transforms unscaled).
 __global__ __launch_bounds__(256) void k_evk_to_f64(const u64* __restrict__ evk, u64* __restrict__ evd,
-                                                     const ntt_limb_t* __restrict__ LT, ks_arg_t KA, int Lk, u32 n, int fold_ninv) {
+                                                     const ntt_limb_t* __restrict__ LT, ks_arg_t KA, int Lk, u32 n, int fold_ninv, int x) {
     const u32 row = blockIdx.x, j = row % (u32)KA.nw, ic = row / (u32)KA.nw;
     const ntt_limb_t& L = LT[KA.w.idx[j]];
     const u64* s = evk + ((size_t)ic * Lk + KA.w.idx[j]) * n;
@@ -1976,7 +1976,9 @@ __global__ __launch_bounds__(256) void k_evk_to_f64(const u64* __restrict__ evk,
         }
         u64 b;
         __builtin_memcpy(&b, &v, 8);
-        d[k] = b;
+        // x > 0 (k_ks_fused_sub at N = 2^16, x = 2): a sub-block reads the words at positions (nat << x) + c -- stored class by
+        // class (c major), so that its lanes read consecutive words instead of every 2^x-th one
+        d[x ? ((size_t)(k & ((1u << x) - 1u)) * (n >> x)) + (k >> x) : k] = b;
     }
 }
 // PRELIFT: the rows of c[end] arrive as centred doubles (bfv_contract_narrow<.., LIFTED>): the lift is a bit cast
@@ -2224,8 +2226,12 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 fwd_compute<A, LOGB, LOGT, K1 + K2, K3, false, true, 0>(v, r3, nullptr, C, tid, pre);
             }
             // multiply-accumulate with the key words at natural-order positions 2 nat + sb
-            const u64* e_mask = evd + ((((size_t)i * 2 + 0) * nw + j) << (LOGB + X)) + brev_bits(sb, X);    // doubles (k_evk_to_f64)
-            const u64* e_masked = evd + ((((size_t)i * 2 + 1) * nw + j) << (LOGB + X)) + brev_bits(sb, X);
+            // (doubles from k_evk_to_f64.  X = 2: stored class by class, the sub-block's words are consecutive -- 33.1 k -> 34.5 k key
+            // switches/s on 7 x 50 bit; at X = 1 the same layout cost 24 more spilled registers and 2.8 % at cfg#3: interleaved there)
+            constexpr bool CM = X == 2;
+            const size_t eoff = CM ? ((size_t)brev_bits(sb, X) << LOGB) : (size_t)brev_bits(sb, X);
+            const u64* e_mask = evd + ((((size_t)i * 2 + 0) * nw + j) << (LOGB + X)) + eoff;
+            const u64* e_masked = evd + ((((size_t)i * 2 + 1) * nw + j) << (LOGB + X)) + eoff;
 #pragma unroll
             for (int u = 0; u < G3::SETS; u++) {
                 u32 c0, hi, base;
@@ -2234,7 +2240,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 for (int r = 0; r < G3::R; r++) {
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
                     const int e = u * G3::R + r;
-                    const typename A::tw k1{A::from_lds(e_masked[nat << X])}, k0{A::from_lds(e_mask[nat << X])};
+                    const typename A::tw k1{A::from_lds(e_masked[CM ? nat : nat << X])}, k0{A::from_lds(e_mask[CM ? nat : nat << X])};
                     const double y = A::pre_product(v[e], C);  // range: as k_ks_fused
                     acc[0][e] += fp_mulmod_c(y, k1, C.p, C.pinv);
                     acc[1][e] += fp_mulmod_c(y, k0, C.p, C.pinv);

@@ -1501,7 +1501,7 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
         KA.w.n = nw;
         for (int j = 0; j < level; j++) KA.w.idx[j] = j;
         if (special) KA.w.idx[level] = Lk - 1;
-        hipLaunchKernelGGL(k_evk_to_f64, row_grid((unsigned)(level * 2 * nw), N), dim3(256), 0, c->stream, evk, evd, c->limbs_dev, KA, Lk, (u32)N, c->logN <= 14 ? 1 : 0);
+        hipLaunchKernelGGL(k_evk_to_f64, row_grid((unsigned)(level * 2 * nw), N), dim3(256), 0, c->stream, evk, evd, c->limbs_dev, KA, Lk, (u32)N, c->logN <= 14 ? 1 : 0, c->logN == 16 ? 2 : 0);
         HIP_TRY(hipGetLastError());
     }
     for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
