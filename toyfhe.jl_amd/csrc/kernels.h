@@ -1507,6 +1507,11 @@ struct ks_keys_t {
                       // leaves as V = S P^-1 (+ X[b][0][j] for s = 0) instead of S (k_md_v folded into the store)
     const u64* key[TFHE_DOT_MAX];
 };
+// Layout of the key sums in the EPI kernels (tfhe_matmul_diag, evaluation-domain form), per ciphertext a block of 2 nw n words:
+// every working limb j holds the two components INTERLEAVED (word j 2n + 2k + s) -- k_md_acc and k_md_special_perm gather both
+// with one 16-byte load per rotated position (a gather costs a cache-line access per lane whatever its width: r04, MNIST pass
+// 73.2 -> 69.0 ms with the ciphertext limbs interleaved).
+__device__ __forceinline__ size_t epi_pair(u32 b, u32 j, u32 k, u32 nw, u32 n) { return ((size_t)b * nw + j) * 2 * n + 2 * (size_t)k; }
 // Several keys in one launch: a 1-D grid in which the workgroups of ONE (limb, tile, batch slice) for all the keys sit next to
 // each other on ONE XCD (workgroup b runs on XCD b & 7): they stream the same digit words at the same time, so the digit rows
 // are fetched from HBM once per launch instead of once per key (the keys and the sums are per key anyway).
@@ -1565,10 +1570,18 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
         for (u32 b0 = b_lo; b0 < b_hi; b0 += 2) {
             const u32 bb[2] = {b0, b0 + 1 < b_hi ? b0 + 1 : b0};
             u64 d[2][DCH], r1[2], r2[2];
+            size_t p1[2], p2[2];   // where the two sums of ciphertext bb[h] live
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                r1[h] = i0 ? S[(((size_t)bb[h] * 2 + 0) * A.nw + j) * n + k] : 0;
-                r2[h] = i0 ? S[(((size_t)bb[h] * 2 + 1) * A.nw + j) * n + k] : 0;
+                if (EPI) {
+                    p1[h] = epi_pair(bb[h], j, k, (u32)A.nw, n);
+                    p2[h] = p1[h] + 1;
+                } else {
+                    p1[h] = (((size_t)bb[h] * 2 + 0) * A.nw + j) * n + k;
+                    p2[h] = (((size_t)bb[h] * 2 + 1) * A.nw + j) * n + k;
+                }
+                r1[h] = i0 ? S[p1[h]] : 0;
+                r2[h] = i0 ? S[p2[h]] : 0;
 #pragma unroll
                 for (int ii = 0; ii < DCH; ii++)
                     if (i0 + ii < A.level) d[h][ii] = dig[(((size_t)bb[h] * A.level + i0 + ii) * A.nw + j) * n + k];
@@ -1603,8 +1616,14 @@ __global__ __launch_bounds__(256) void k_ks_inner(const u64* __restrict__ evk, c
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (h == 0 || bb[1] != bb[0]) {
-                    S[(((size_t)bb[h] * 2 + 0) * A.nw + j) * n + k] = r1[h];
-                    S[(((size_t)bb[h] * 2 + 1) * A.nw + j) * n + k] = r2[h];
+                    if (EPI) {
+                        u64x2_t w;
+                        w.x = r1[h]; w.y = r2[h];
+                        *(u64x2_t*)(S + p1[h]) = w;
+                    } else {
+                        S[p1[h]] = r1[h];
+                        S[p2[h]] = r2[h];
+                    }
                 }
             }
         }
@@ -1645,10 +1664,21 @@ __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk
             }
         }
         for (u32 b = b_lo; b < b_hi; b++) {
-            u64x2_t* s1p = (u64x2_t*)(S + (((size_t)b * 2 + 0) * A.nw + j) * n + k);
-            u64x2_t* s2p = (u64x2_t*)(S + (((size_t)b * 2 + 1) * A.nw + j) * n + k);
+            // EPI: the two components interleaved (epi_pair): words {s1[k], s2[k]}, {s1[k+1], s2[k+1]}
+            constexpr bool pairs = EPI;
+            u64x2_t *s1p, *s2p;
+            if (EPI) {
+                s1p = (u64x2_t*)(S + epi_pair(b, j, k, (u32)A.nw, n));
+                s2p = s1p + 1;
+            } else {
+                s1p = (u64x2_t*)(S + (((size_t)b * 2 + 0) * A.nw + j) * n + k);
+                s2p = (u64x2_t*)(S + (((size_t)b * 2 + 1) * A.nw + j) * n + k);
+            }
             u64x2_t p1 = {0, 0}, p2 = {0, 0};
-            if (i0) { p1 = *s1p; p2 = *s2p; }
+            if (i0) {
+                p1 = *s1p; p2 = *s2p;
+                if (pairs) { const u64x2_t a = p1, c = p2; p1.x = a.x; p1.y = c.x; p2.x = a.y; p2.y = c.y; }
+            }
             acc52 s1[2] = {{p1[0], 0, 0}, {p1[1], 0, 0}}, s2[2] = {{p2[0], 0, 0}, {p2[1], 0, 0}};
             u64x2_t dv[DCH];
 #pragma unroll
@@ -1684,8 +1714,15 @@ __global__ __launch_bounds__(256) void k_ks_inner_n2(const u64* __restrict__ evk
                     }
                 }
             }
-            *s1p = r1;
-            *s2p = r2;
+            if (pairs) {
+                u64x2_t a, c;
+                a.x = r1[0]; a.y = r2[0]; c.x = r1[1]; c.y = r2[1];
+                *s1p = a;
+                *s2p = c;
+            } else {
+                *s1p = r1;
+                *s2p = r2;
+            }
         }
     }
 }
@@ -2498,12 +2535,13 @@ __global__ __launch_bounds__(256) void k_ks_rot_tail(const u64* __restrict__ T, 
 // floor takes is the rotated polynomial's), its lift costs `level` forward transforms per sum -- which the coefficient-domain
 // path also spends, on the rotated ciphertext -- and the `level` inverse transforms per sum of that path are not needed.
 // Every step is exact modular arithmetic on canonical residues: the accumulated product is bit-identical.
-//   k_md_special_perm   P[grp]      = S'[grp][special] o pi_g            (XCD-cooperative gather, grp = (r * batch + b) * 2 + s)
+//   k_md_special_perm   P[grp]      = S'[grp][special] o pi_g            (XCD-cooperative gather, grp = (r * batch + b) * 2 + s; both s at once)
 //   (inverse transform of P on the special limb)
 //   k_md_lift           U[grp][j]   = ([P[grp]] mod q_j) P^-1             (unsigned representative, crt.jl:215-220)
 //   (forward transforms of U; where md_lift_is_fused the lift rides on their loads -- ntt_io_t::lift_unsigned -- and k_md_acc
 //   multiplies by P^-1 itself: USCALE)
-//   (V[grp][j] = S'[grp][j] P^-1 + X0[b][j] [s = 0] is what the key-sum kernels store for j < level: k_ks_inner<.., EPI>)
+//   (V[grp][j] = S'[grp][j] P^-1 + X0[b][j] [s = 0] is what the key-sum kernels store for j < level: k_ks_inner<.., EPI>, the two
+//   components s = 0, 1 of a position interleaved -- epi_pair)
 //   k_md_acc            out[b][s][j][k] = diag_0[j][k] X[b][s][j][k] + sum_r diag_{r+1}[j][k] (V[grp][j][pi_r k] - U[grp][j][k])
 // The gathers are XCD-cooperative (one row per XCD at a time, as k_ks_rot_tail): a permutation uses every cache line of its
 // 8 N-byte window 16 times, so the window has to stay in one L2 until the row is done.
@@ -2514,11 +2552,15 @@ __global__ __launch_bounds__(256) void k_md_special_perm(const u64* __restrict__
     // small rows: an XCD's workgroups split into teams of n / 256 (a row each) instead of idling beyond the row
     const u32 spt = n / blockDim.x >= nslot ? nslot : (n / blockDim.x ? n / blockDim.x : 1u), teams = nslot / spt, team = slot / spt, ts = slot % spt;
     if (team >= teams) return;
-    for (u32 grp = team * 8u + xcd; grp < ngroups; grp += 8u * teams) {
-        const u64 g = G.g[(grp >> 1) / batch];
-        const u64* s = S + ((size_t)grp * nw + level) * n;
-        u64* d = P + (size_t)grp * n;
-        for (u32 m = ts * blockDim.x + threadIdx.x; m < n; m += spt * blockDim.x) d[m] = s[galois_ntt_pos(m, g, n)];
+    for (u32 ci = team * 8u + xcd; ci < ngroups / 2u; ci += 8u * teams) {   // ciphertext ci = r * batch + b: both components together
+        const u64 g = G.g[ci / batch];
+        const u64x2_t* s = (const u64x2_t*)(S + epi_pair(ci, level, 0u, nw, n));   // (the EPI kernels' layout of the sums)
+        u64 *d0 = P + (size_t)(2u * ci) * n, *d1 = d0 + n;
+        for (u32 m = ts * blockDim.x + threadIdx.x; m < n; m += spt * blockDim.x) {
+            const u64x2_t w = s[galois_ntt_pos(m, g, n)];
+            d0[m] = w.x;
+            d1[m] = w.y;
+        }
     }
 }
 // rows = ngroups * level, row = grp * level + j
@@ -2572,12 +2614,13 @@ __global__ __launch_bounds__(256) void k_md_acc(const u64* __restrict__ X, const
             auto fetch = [&](u32 t, term_t& T) {
                 const size_t g0 = (size_t)t * gstride + (size_t)b * 2;
                 const u64 g = G.g[t];
-                const u64 *pv0 = V + (g0 * nw + j) * n, *pv1 = V + ((g0 + 1) * nw + j) * n;
+                const u64x2_t* pv = (const u64x2_t*)(V + epi_pair((u32)(g0 >> 1), j, 0u, nw, n));   // both components of a position: one gather
                 const u64 *pu0 = U + (g0 * level + j) * n, *pu1 = U + ((g0 + 1) * level + j) * n, *pd = dj + (size_t)(t + 1) * dstride;
 #pragma unroll
                 for (int i = 0; i < KB; i++) {
                     const u32 kk = galois_ntt_pos(k[i], g, n);
-                    T.v0[i] = pv0[kk]; T.v1[i] = pv1[kk]; T.u0[i] = pu0[k[i]]; T.u1[i] = pu1[k[i]]; T.d[i] = pd[k[i]];
+                    const u64x2_t vv = pv[kk];
+                    T.v0[i] = vv.x; T.v1[i] = vv.y; T.u0[i] = pu0[k[i]]; T.u1[i] = pu1[k[i]]; T.d[i] = pd[k[i]];
                 }
             };
             acc128 a0[KB], a1[KB];
