@@ -931,6 +931,46 @@ def test_recycling_allocator_reuses_blocks_without_draining_the_device():
     assert s2["cached_bytes"] == 0
 
 
+def test_allocator_holds_back_a_host_that_runs_far_ahead():
+    """csrc/dev_alloc.h back-pressure: a host that enqueues far ahead of the device frees its temporaries long before their release
+    events complete, so nothing is ready when the same sizes are requested again.  Past the soft threshold a request waits for
+    the oldest parked block of its size instead of allocating -- the cache stays near the threshold (here 64 MiB, set through
+    TFHE_ALLOC_SOFT_GIB in a fresh process) instead of growing by a block per operation, and the results are the same."""
+    import os, subprocess, sys, textwrap
+    if os.environ.get("TFHE_ALLOC_CACHE", "1") == "0":
+        pytest.skip("the recycling allocator is switched off (TFHE_ALLOC_CACHE=0)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import toyfhe_jl_amd as tf
+        from tests import helpers as H
+        from oracle import ref_cpu
+        N = 1 << 14
+        qs = H.chain(50, 4, N)
+        ctx, ref = tf.Context(N, qs), ref_cpu.RefCtx(N, qs)
+        rng = np.random.default_rng(3)
+        a = H.rand_residues(rng, qs, (8,), N)                 # 4 MiB per buffer
+        cur = tf.DeviceBuffer.from_numpy(a)
+        for i in range(600):                                  # a chain of transforms, each into a fresh buffer; the old one is dropped
+            o = tf.DeviceBuffer(a.size)
+            if i %% 2 == 0: ctx.nntt(cur.ptr, o.ptr, 8, 4)
+            else: ctx.inntt(cur.ptr, o.ptr, 8, 4)
+            cur = o
+        s = tf.native.alloc_stats()
+        got = cur.to_numpy(a.shape)
+        assert np.array_equal(got, a), "600 transforms = 300 round trips"
+        print("STATS", s["cached_bytes"] + s["live_bytes"], s["hip_mallocs"])
+    ''' % root)
+    env = dict(os.environ, TFHE_ALLOC_SOFT_GIB="0.0625")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("STATS")][-1].split()
+    held, mallocs = int(line[1]), int(line[2])
+    assert held <= (64 << 20) + 16 * (4 << 20), held        # the threshold plus a few blocks, not 600 x 4 MiB
+    assert mallocs <= 64, mallocs
+
+
 @pytest.mark.parametrize("special", [True, False])
 def test_fused_keyswitch_at_2_13_many_items(special):
     """N = 2^13 on the 256 x 32 geometry: the fused key switch with two workgroups per CU walking several (ciphertext, limb)

@@ -11,6 +11,9 @@
 //                   fallback when an event cannot be created or recorded (a stream the caller destroyed): a plain hipFree.
 //   tfhe_malloc(n): polls the parked blocks in FIFO order (events complete in order), then hands out a ready block of the
 //                   same size, or falls back to hipMalloc; on out-of-memory the cache is drained and the call retried.
+//                   Once the cache holds more than a soft threshold (a quarter of its bound; TFHE_ALLOC_SOFT_GIB) a request
+//                   that finds nothing ready waits for the oldest PARKED block of its size instead of allocating: a host
+//                   far ahead of the device is held back by memory, it does not run the cache into its bound.
 //
 // So a recycled block is never handed out while a kernel enqueued before its tfhe_free can still touch it, whatever stream
 // the next user runs on.  TFHE_ALLOC_CACHE=0 in the environment restores plain hipMalloc / hipFree.
@@ -53,7 +56,9 @@ struct dev_state_t {  // the cache of one device
     std::unordered_map<size_t, std::vector<void*>> ready;        // size -> recyclable blocks
     std::deque<parked_t> parked;                                 // freed, waiting for their events
     std::vector<hipEvent_t> ev_pool;                             // events of this device
-    size_t cached_bytes = 0, max_cached = 0;
+    std::unordered_map<size_t, unsigned long> last_use;          // size -> sequence number of the last request for it
+    unsigned long seq = 0;
+    size_t cached_bytes = 0, max_cached = 0, soft_cached = 0;
     bool want_trim = false;                                      // the cache passed its bound in release(): trimmed by the next alloc()
 };
 
@@ -88,6 +93,12 @@ inline dev_state_t& dev_locked(state_t& s, int dev) {
         d.max_cached = (size_t)96 << 30;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) d.max_cached = std::min(d.max_cached, tot / 3);
         else (void)hipGetLastError();
+        // back-pressure threshold (alloc): a quarter of the bound, TFHE_ALLOC_SOFT_GIB overrides (fractions allowed)
+        d.soft_cached = d.max_cached / 4;
+        if (const char* e = getenv("TFHE_ALLOC_SOFT_GIB")) {
+            const double g = atof(e);
+            if (g > 0.0) d.soft_cached = std::min(d.max_cached, (size_t)(g * (double)((size_t)1 << 30)));
+        }
     }
     return d;
 }
@@ -153,9 +164,26 @@ inline hipError_t malloc_retry(T** out, size_t bytes) {
     return e;
 }
 
+// ready blocks of sizes nobody has asked for during the last STALE_AFTER requests (left by an earlier phase of the program) back
+// to the driver (hipFree drains the device; parked blocks and the sizes in use stay)
+constexpr unsigned long STALE_AFTER = 4096;
+inline void free_stale_ready_locked(state_t& s, dev_state_t& d) {
+    for (auto it = d.ready.begin(); it != d.ready.end();) {
+        auto lu = d.last_use.find(it->first);
+        if (lu != d.last_use.end() && lu->second + STALE_AFTER >= d.seq) { ++it; continue; }
+        for (void* p : it->second) {
+            (void)hipFree(p);
+            d.cached_bytes -= it->first;
+            s.cached_bytes -= it->first;
+        }
+        if (lu != d.last_use.end()) d.last_use.erase(lu);
+        it = d.ready.erase(it);
+    }
+}
+
 inline hipError_t alloc(size_t bytes, void** out) {
     state_t& s = S();
-    std::lock_guard<std::mutex> g(s.mu);
+    std::unique_lock<std::mutex> g(s.mu);
     lazy_init(s);
     if (bytes == 0) bytes = 8;
     if (!s.enabled) return hipMalloc(out, bytes);
@@ -166,7 +194,30 @@ inline hipError_t alloc(size_t bytes, void** out) {
         if (d.cached_bytes > d.max_cached) trim_locked(s);
     }
     poll_locked(d);
+    d.last_use[bytes] = ++d.seq;
     auto it = d.ready.find(bytes);
+    if ((it == d.ready.end() || it->second.empty()) && d.cached_bytes > d.soft_cached) {
+        // Back-pressure (r04).  A host that enqueues far ahead of the device frees blocks long before their release events complete:
+        // nothing is ready when the same sizes are asked for again, every request becomes a hipMalloc, the cache runs into its bound
+        // and is trimmed wholesale (device drain + hipFree + hipMalloc of everything, once per pass: the chained-rotation MNIST
+        // circuit went from 0.29 s to 2.5 s per pass that way).  Past the soft threshold: first give back ready blocks of sizes
+        // that have gone out of use (left by an earlier phase), then WAIT for the oldest parked block of this size instead of
+        // allocating -- the host stays ahead of the device by the blocks it already owns, not by ever more memory.
+        free_stale_ready_locked(s, d);
+        if (d.cached_bytes > d.soft_cached) {
+            std::vector<hipEvent_t> evs;
+            for (const parked_t& b : d.parked)
+                if (b.p && b.bytes == bytes) { evs = b.evs; break; }
+            if (!evs.empty()) {
+                g.unlock();                                      // release() on other threads must not wait behind this
+                for (hipEvent_t ev : evs)
+                    if (hipEventSynchronize(ev) != hipSuccess) (void)hipGetLastError();
+                g.lock();
+                poll_locked(d);
+            }
+        }
+        it = d.ready.find(bytes);
+    }
     if (it != d.ready.end() && !it->second.empty()) {
         *out = it->second.back();
         it->second.pop_back();
