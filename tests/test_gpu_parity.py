@@ -530,6 +530,41 @@ def test_rotate_many_equals_individual_rotations(N, qspec, batch, special):
         ctx.rotate_many(Lk, level, special, [devks[0].ptr], Lk, [4], dct.ptr, out.ptr, batch)   # even element
 
 
+@pytest.mark.parametrize("special", [True, False])
+@pytest.mark.parametrize("N,qspec", [(1 << 15, "40x4"), (1 << 15, "50x3"), (1 << 16, "50x3"), (1 << 16, "mixed")])
+def test_rotation_finished_in_the_tail(N, qspec, special):
+    """tfhe_rotate at N = 2^15 / 2^16 on enough ciphertexts (>= 8) takes no rotated copy of its input: the key is prepared on the
+    way, the key sums are those of the unrotated digits and the automorphism rides on the tail's stores (k_ks_top_tail_rot, signs
+    before the ModulusRaised floor).  Against the hoisted path (tfhe_rotate_many: inverse transform, automorphism pass, tail --
+    other kernels throughout) on every ciphertext, and against the oracle's rotate = keyswitch o apply_galois_element
+    (rlwe_she.jl:355-359) on two of them; a Galois element with many sign wraps and the conjugation."""
+    if qspec == "mixed":
+        qs = H.chain(60, 1, N) + H.chain(40, 2, N) + [H.chain(60, 2, N)[1]]
+    else:
+        bits, n = qspec.split("x")
+        qs = H.chain(int(bits), int(n), N)
+    Lk = len(qs)
+    level = Lk - 1 if special else Lk
+    batch = 9
+    ctx, ref = tf.Context(N, qs), ref_cpu.RefCtx(N, qs)
+    rng = np.random.default_rng(N % 1000 + 7 * special + len(qspec))
+    ct = H.rand_residues(rng, qs[:level], (batch, 2), N)
+    for l in range(level):   # zeros (no sign to flip), the centring edges
+        ct[0, :, l, :6] = [0, 1, qs[l] - 1, qs[l] // 2, qs[l] // 2 + 1, 0]
+    dct = dev(ct)
+    for g in (pow(3, N // 2 + 3, 2 * N), 2 * N - 1):
+        evk = H.uniform_evk(rng, qs, Lk, N)
+        devk = dev(evk)
+        one, many = tf.DeviceBuffer(batch * 2 * level * N), tf.DeviceBuffer(batch * 2 * level * N)
+        ctx.rotate(Lk, level, special, devk.ptr, Lk, g, dct.ptr, one.ptr, batch)
+        ctx.rotate_many(Lk, level, special, [devk.ptr], Lk, [g], dct.ptr, many.ptr, batch)
+        got = one.to_numpy((batch, 2, level, N))
+        assert np.array_equal(got, many.to_numpy((batch, 2, level, N))), g
+        pick = [0, batch - 1]
+        want = ref.keyswitch(level, special, evk, ref.galois(g, ct[pick].reshape(-1, level, N), idx=range(level)).reshape(ct[pick].shape))
+        assert np.array_equal(got[pick], want), g
+
+
 @pytest.mark.parametrize("special", [False, True])
 def test_rotate_full_degree_matches_oracle(special):
     """rotate = keyswitch o apply_galois_element (rlwe_she.jl:355-359) at N = 2^14 -- the fused key-switch kernel behind the

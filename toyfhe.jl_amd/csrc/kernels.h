@@ -2000,13 +2000,16 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_quad2(const u64* __restri
 // fused kernel's inner product, where every word is used once per ciphertext of the batch.
 // fold_ninv: the words are multiplied by N^-1 mod q_j on the way (k_ks_fused runs its inverse transforms unscaled).
 __global__ __launch_bounds__(256) void k_evk_to_f64(const u64* __restrict__ evk, u64* __restrict__ evd,
-                                                     const ntt_limb_t* __restrict__ LT, ks_arg_t KA, int Lk, u32 n, int fold_ninv, int x) {
+                                                     const ntt_limb_t* __restrict__ LT, ks_arg_t KA, int Lk, u32 n, int fold_ninv, int x,
+                                                     u64 ginv) {
     const u32 row = blockIdx.x, j = row % (u32)KA.nw, ic = row / (u32)KA.nw;
     const ntt_limb_t& L = LT[KA.w.idx[j]];
     const u64* s = evk + ((size_t)ic * Lk + KA.w.idx[j]) * n;
     u64* d = evd + (size_t)row * n;
     for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < n; k += gridDim.y * blockDim.x) {
-        double v = fp_from_u64(s[k]);
+        // ginv != 0: the key of x -> x^g PREPARED on the way (rows permuted by g^-1, as tfhe_galois_key_prepare) -- the rotation in the
+        // tail (k_ks_top_tail_rot): the key sums of the UNrotated digits are then sigma_g^-1 of the rotated ciphertext's
+        double v = fp_from_u64(s[ginv ? galois_ntt_pos(k, ginv, n) : k]);
         if (fold_ninv) {
             v = fp_mulmod_c(v, L.ninv_d, L.pd, L.pinvd);
             v = v < 0.0 ? v + L.pd : v;
@@ -2711,6 +2714,74 @@ __global__ __launch_bounds__(256) void k_ks_top_tail(const u64* __restrict__ T, 
                 u64 x = v[r];
                 if (c) x = addmod(x, c[k + (u32)r * stride], q);
                 o[k + (u32)r * stride] = x;
+            }
+        }
+    }
+}
+
+// The same tail for a ROTATION whose key sums were formed from the UNrotated ciphertext against the prepared key (hoisting
+// identity, tfhe_rotate_many): T holds sigma_g^-1 of the sums, so coefficient i of every limb -- and of the addend c_s, read
+// straight from the unrotated input -- goes to position i g mod 2N with the sign of the wrap (pow2_cyc_rings.jl:321-329),
+// BEFORE the ModulusRaised floor (it does not commute with the sign).  No rotated copy of the input is ever made: the separate
+// automorphism pass over the polys x level input rows (k_galois_xcd: 9 % of a rotation at cfg#3) is gone; what it cost in
+// scattered 8-byte stores moves into this kernel's final stores.  XCD-cooperative like k_galois_xcd: the workgroups of one XCD
+// share one (ciphertext, component) -- its `level` output rows, one index map -- at a time, so the scattered stores land in
+// windows that stay in that XCD's L2 until they are complete; the special limb's sub-block words are read once per
+// coefficient, not once per limb.
+template <int X>
+__global__ __launch_bounds__(256) void k_ks_top_tail_rot(const u64* __restrict__ T, const u64* __restrict__ ct, u64* __restrict__ out,
+                                                          const ntt_limb_t* __restrict__ LT, ks_arg_t A, rescale_arg_t ra, u32 n,
+                                                          u32 add_s, u64 g, u32 npairs) {
+    constexpr int R = 1 << X;
+    const u32 xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const u32 stride = n >> X, level = (u32)A.level;
+    // an XCD's workgroups beyond the stride / 256 that cover the coefficient groups once form further teams: team t takes the limbs
+    // j = t, t + teams, ... (the special limb's words are re-read per team, from L2)
+    const u32 spt = (stride + blockDim.x - 1) / blockDim.x < nslot ? (stride + blockDim.x - 1) / blockDim.x : nslot, teams = nslot / spt;
+    const u32 team = slot / spt, ts = slot % spt;
+    if (team >= teams) return;
+    const u64 mask2n = 2ull * n - 1;
+    const ntt_limb_t LP = LT[A.w.idx[A.special ? level : 0]];
+    for (u32 pr = xcd; pr < npairs; pr += 8u) {   // pr = b * 2 + s
+        const u32 s = pr & 1u, b = pr >> 1;
+        const u64* tl = T + ((size_t)pr * A.nw + level) * n;
+        for (u32 k = ts * blockDim.x + threadIdx.x; k < stride; k += spt * blockDim.x) {
+            u64 p[R];
+            u32 m[R];
+            bool neg[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const u64 t = ((u64)(k + (u32)r * stride) * g) & mask2n;
+                neg[r] = t >= n;
+                m[r] = (u32)t & (n - 1u);
+            }
+            if (A.special) {
+#pragma unroll
+                for (int r = 0; r < R; r++) p[r] = tl[k + (u32)r * stride];
+                ntt_inv_top_regs<X>(p, LP);
+#pragma unroll
+                for (int r = 0; r < R; r++) p[r] = neg[r] ? negmod(p[r], LP.q) : p[r];   // the rotated polynomial's unsigned representative
+            }
+            for (u32 j = team; j < level; j += teams) {
+                const ntt_limb_t& L = LT[A.w.idx[j]];
+                const u64 q = L.q;
+                const u64* tj = T + ((size_t)pr * A.nw + j) * n;
+                const u64* c = s < add_s ? ct + (((size_t)b * A.polys + s) * level + j) * n : nullptr;
+                u64* o = out + ((size_t)pr * level + j) * n;
+                u64 v[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) v[r] = tj[k + (u32)r * stride];
+                ntt_inv_top_regs<X>(v, L);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    u64 x = neg[r] ? negmod(v[r], q) : v[r];
+                    if (A.special) x = shoup_full(submod(x, barrett_reduce128(p[r], 0, L.br), q), ra.qlinv[j], q);
+                    if (c) {
+                        const u64 cv = c[k + (u32)r * stride];
+                        x = addmod(x, neg[r] ? negmod(cv, q) : cv, q);
+                    }
+                    o[m[r]] = x;
+                }
             }
         }
     }

@@ -1233,8 +1233,15 @@ static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* ev
 // g^-1), so the sums are those of the rotated digits up to that permutation: S' = sigma_g^-1(S).  The automorphism is applied
 // to INTT(S') in the coefficient domain (a signed permutation) BEFORE the tail -- the ModulusRaised floor does not commute
 // with sign changes -- into `tbuf`, which must not alias the digits (they are reused by the next rotation).
+// whether ks_finish takes the N = 2^16 path (paired sub-block inverse + k_ks_top_tail<2>)
+static bool ks_tail16(const tfhe_ctx* c, const ks_arg_t& A) {
+    const u32 fpm = mask_of(A.nw, [&](int j) { return c->limbs_host[A.w.idx[j]].Wd != nullptr; });
+    return c->logN == 16 && c->variant == 0 && fpm != 0 && A.level >= 2;
+}
+// g_tail != 0: a rotation finished in the tail (k_ks_top_tail_rot<2>; N = 2^16 path only): `evk` is the prepared key, `ct` the
+// UNrotated input
 static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, const u64* ct, u64* out, int64_t batch, u64* S,
-                     const u64* dig, u64* tbuf, u64 g) {
+                     const u64* dig, u64* tbuf, u64 g, u64 g_tail = 0) {
     const int level = A.level, nw = A.nw, polys = A.polys, special = A.special;
     const u32 n = (u32)c->N;
     const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
@@ -1263,7 +1270,9 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
         return TFHE_OK;
     }
     const u32 fpm = mask_of(nw, [&](int j) { return c->limbs_host[A.w.idx[j]].Wd != nullptr; });
-    if (c->logN == 16 && c->variant == 0 && fpm != 0 && level >= 2 && (((uintptr_t)S | (uintptr_t)tbuf) & 15u) == 0) {
+    const bool tail16 = ks_tail16(c, A) && (((uintptr_t)S | (uintptr_t)tbuf) & 15u) == 0;
+    if (g_tail && !tail16) return fail(TFHE_E_UNSUPPORTED, "internal: rotation in the tail needs the N = 2^16 sub-block path");
+    if (tail16) {
         // N = 2^16: the paired sub-block inverse into the (now free) digit buffer, then the two inverse top stages together with
         // the tail (k_ks_top_tail<2>) instead of k_ntt_inv_top<2> + k_ks_rescale_add / k_ks_add_ct.  Rings of mixed modulus sizes:
         // the larger limbs' sub-blocks come from the u64 block kernel (same sub-block layout, lazy [0, 2q) outputs).
@@ -1281,7 +1290,8 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
             const u64 P = c->q[Lk - 1];
             for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
         }
-        hipLaunchKernelGGL(k_ks_top_tail<2>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 4), dim3(256), 0, c->stream, tbuf, ct, out, c->limbs_dev, A, ra, n, add_s);
+        if (g_tail) hipLaunchKernelGGL(k_ks_top_tail_rot<2>, dim3(8 * TFHE_ROT_TAIL_SLOTS), dim3(256), 0, c->stream, tbuf, ct, out, c->limbs_dev, A, ra, n, add_s, g_tail, (u32)(batch * 2));
+        else hipLaunchKernelGGL(k_ks_top_tail<2>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 4), dim3(256), 0, c->stream, tbuf, ct, out, c->limbs_dev, A, ra, n, add_s);
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
@@ -1309,8 +1319,9 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
     return TFHE_OK;
 }
 
+// g_tail != 0: a rotation finished in the tail (k_ks_top_tail_rot) -- `ct` is the UNrotated input and `evd` was prepared for g
 static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
-                    u64* S, u64* dig, const u64* evd, bool prelifted) {
+                    u64* S, u64* dig, const u64* evd, bool prelifted, u64 g_tail = 0) {
     const int nw = special ? level + 1 : level;
     ks_arg_t A;
     memset(&A, 0, sizeof A);
@@ -1448,14 +1459,18 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
             const u64 P = c->q[Lk - 1];
             for (int j = 0; j < level; j++) ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(P % c->q[j], c->q[j]), c->q[j]);
         }
-        if (x == 1) hipLaunchKernelGGL(k_ks_top_tail<1>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 2), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
+        if (g_tail) {   // rotation: the automorphism rides on the tail's stores (XCD-cooperative scatter)
+            const dim3 rg(8 * TFHE_ROT_TAIL_SLOTS);
+            if (x == 1) hipLaunchKernelGGL(k_ks_top_tail_rot<1>, rg, dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s, g_tail, (u32)(batch * 2));
+            else hipLaunchKernelGGL(k_ks_top_tail_rot<2>, rg, dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s, g_tail, (u32)(batch * 2));
+        } else if (x == 1) hipLaunchKernelGGL(k_ks_top_tail<1>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 2), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
         else hipLaunchKernelGGL(k_ks_top_tail<2>, row_grid((unsigned)(batch * 2 * level), (size_t)c->N / 4), dim3(256), 0, c->stream, dig, ct, out, c->limbs_dev, A, ra, n, add_s);
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
     rc = ks_digits_fwd(c, A, ct, dig, batch);
     if (rc) return rc;
-    return ks_finish(c, A, Lk, evk, ct, out, batch, S, dig, dig, 0);
+    return ks_finish(c, A, Lk, evk, ct, out, batch, S, dig, dig, 0, g_tail);
 }
 
 static int ks_check(tfhe_ctx* c, int Lk, int level, int special, const void* evk, int n_digits, const void* ct, int polys, const void* out, int64_t batch) {
@@ -1469,12 +1484,30 @@ static int ks_check(tfhe_ctx* c, int Lk, int level, int special, const void* evk
     return TFHE_OK;
 }
 
+static u64 inv_mod_2n(u64 g, u64 twoN);
 static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
                           u64 galois, bool rotate, bool prelifted = false) {
     if (prelifted && (rotate || special || !ks_prelift_ok(c, level))) return fail(TFHE_E_UNSUPPORTED, "internal: pre-lifted rows need the fused key switch");
     const int nw = special ? level + 1 : level;
     const size_t N = (size_t)c->N;
     const bool f14 = ks_fused14(c, Lk, level, special);
+    // Rotations through the sub-block fused key switch (N = 2^15 / 2^16): no rotated copy of the input -- the key is prepared while
+    // it is converted (k_evk_to_f64), the key sums are those of the unrotated digits, the automorphism rides on the tail's stores
+    // (k_ks_top_tail_rot).  Same bits (the hoisting identity of tfhe_rotate_many).  TFHE_ROT_TAIL=0 keeps the separate pass.
+    static const bool rot_tail_on = !(getenv("TFHE_ROT_TAIL") && getenv("TFHE_ROT_TAIL")[0] == '0');
+    bool rot_in_tail = rotate && f14 && c->logN >= 15 && rot_tail_on && out != ct && batch >= 8;   // (one (ciphertext, component) per XCD at a time)
+    // the same for the N = 2^16 three-kernel path (rings with moduli beyond the fp64 size: the reference's CKKS ring): the key is
+    // prepared into the workspace (k_ntt_perm), the rotation rides on k_ks_top_tail_rot<2>
+    bool rot_key_prep = false;
+    if (rotate && !f14 && rot_tail_on && out != ct && batch >= 8) {
+        ks_arg_t KA;
+        memset(&KA, 0, sizeof KA);
+        KA.level = level; KA.nw = nw;
+        KA.w.n = nw;
+        for (int j = 0; j < level; j++) KA.w.idx[j] = j;
+        if (special) KA.w.idx[level] = Lk - 1;
+        if (ks_tail16(c, KA)) rot_in_tail = rot_key_prep = true;
+    }
     // chunk the batch so that the digit tensor stays at a few GiB.  The fused key switches (ks_fused14) never write the digit
     // rows: at N = 2^15 the "digit" buffer only carries the sub-block sums T (2 nw rows per ciphertext), so a whole batch is one
     // launch (cfg#3, 512 ciphertexts: 248 + 248 + 16 before -- the 16 ran as two nearly empty item rounds of k_ks_fused_sub)
@@ -1485,7 +1518,8 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
     // NTT of N > 2^14 uses the context workspace as well: keep ours separate by over-allocating (the fused paths run no
     // stand-alone transform)
     const size_t ntt_tmp = (c->logN > 14 && !f14) ? (size_t)chunk * std::max(2, level) * nw * N * 8 : 0;
-    const size_t evd_bytes = f14 ? (size_t)level * 2 * nw * N * 8 : 0;  // the key rows of this call as doubles
+    const size_t evd_bytes = f14 ? (size_t)level * 2 * nw * N * 8                  // the key rows of this call as doubles
+                                 : (rot_key_prep ? (size_t)level * 2 * Lk * N * 8 : 0);   // ... or the prepared key of a rotation
     int rc = ensure_ws(c, ntt_tmp + chunk * per_ct + evd_bytes, &ws);
     if (rc) return rc;
     u64* base = (u64*)((char*)ws + ntt_tmp);
@@ -1501,13 +1535,20 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
         KA.w.n = nw;
         for (int j = 0; j < level; j++) KA.w.idx[j] = j;
         if (special) KA.w.idx[level] = Lk - 1;
-        hipLaunchKernelGGL(k_evk_to_f64, row_grid((unsigned)(level * 2 * nw), N), dim3(256), 0, c->stream, evk, evd, c->limbs_dev, KA, Lk, (u32)N, c->logN <= 14 ? 1 : 0, c->logN == 16 ? 2 : 0);
+        hipLaunchKernelGGL(k_evk_to_f64, row_grid((unsigned)(level * 2 * nw), N), dim3(256), 0, c->stream, evk, evd, c->limbs_dev, KA, Lk, (u32)N, c->logN <= 14 ? 1 : 0, c->logN == 16 ? 2 : 0,
+                           rot_in_tail ? inv_mod_2n(galois, 2 * (u64)c->N) : (u64)0);
         HIP_TRY(hipGetLastError());
+    }
+    if (rot_key_prep) {
+        u64* keyp = (u64*)((char*)ws + ntt_tmp + chunk * per_ct);
+        hipLaunchKernelGGL(k_ntt_perm, row_grid((unsigned)(level * 2 * Lk), N), dim3(256), 0, c->stream, evk, keyp, inv_mod_2n(galois, 2 * (u64)c->N), (u32)N);
+        HIP_TRY(hipGetLastError());
+        evk = keyp;
     }
     for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
         const int64_t nb = std::min(chunk, batch - b0);
         const u64* cin = ct + (size_t)b0 * polys * level * N;
-        if (rotate) {
+        if (rotate && !rot_in_tail) {
             limb_sel_t s;
             s.n = level;
             for (int j = 0; j < level; j++) s.idx[j] = j;
@@ -1515,7 +1556,7 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
             if (rc) return rc;
             cin = rot;
         }
-        rc = ks_chunk(c, Lk, level, special, evk, cin, polys, out + (size_t)b0 * 2 * level * N, nb, acc, dig, evd, prelifted);
+        rc = ks_chunk(c, Lk, level, special, evk, cin, polys, out + (size_t)b0 * 2 * level * N, nb, acc, dig, evd, prelifted, rot_in_tail ? galois : (u64)0);
         if (rc) return rc;
     }
     return TFHE_OK;
