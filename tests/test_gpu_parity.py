@@ -531,13 +531,15 @@ def test_rotate_many_equals_individual_rotations(N, qspec, batch, special):
 
 
 @pytest.mark.parametrize("special", [True, False])
-@pytest.mark.parametrize("N,qspec", [(1 << 15, "40x4"), (1 << 15, "50x3"), (1 << 16, "50x3"), (1 << 16, "mixed")])
+@pytest.mark.parametrize("N,qspec", [(1 << 14, "50x4"), (1 << 15, "40x4"), (1 << 15, "50x3"), (1 << 16, "50x3"), (1 << 16, "mixed")])
 def test_rotation_finished_in_the_tail(N, qspec, special):
     """tfhe_rotate at N = 2^15 / 2^16 on enough ciphertexts (>= 8) takes no rotated copy of its input: the key is prepared on the
     way, the key sums are those of the unrotated digits and the automorphism rides on the tail's stores (k_ks_top_tail_rot, signs
     before the ModulusRaised floor).  Against the hoisted path (tfhe_rotate_many: inverse transform, automorphism pass, tail --
     other kernels throughout) on every ciphertext, and against the oracle's rotate = keyswitch o apply_galois_element
-    (rlwe_she.jl:355-359) on two of them; a Galois element with many sign wraps and the conjugation."""
+    (rlwe_she.jl:355-359) on two of them; a Galois element with many sign wraps and the conjugation.  At N = 2^14 with the special
+    prime the rotation rides on the in-kernel contraction's stores (k_ks_fused SPMODE 3), on more ciphertexts than workgroups; the
+    hoisted path is reached there through a prepared key."""
     if qspec == "mixed":
         qs = H.chain(60, 1, N) + H.chain(40, 2, N) + [H.chain(60, 2, N)[1]]
     else:
@@ -545,7 +547,7 @@ def test_rotation_finished_in_the_tail(N, qspec, special):
         qs = H.chain(int(bits), int(n), N)
     Lk = len(qs)
     level = Lk - 1 if special else Lk
-    batch = 9
+    batch = 70 if N == 1 << 14 else 9      # 70 x 3 limbs = 210 items + 70 special-limb items on 256 workgroups, then > 1 item each at level 4
     ctx, ref = tf.Context(N, qs), ref_cpu.RefCtx(N, qs)
     rng = np.random.default_rng(N % 1000 + 7 * special + len(qspec))
     ct = H.rand_residues(rng, qs[:level], (batch, 2), N)
@@ -557,7 +559,12 @@ def test_rotation_finished_in_the_tail(N, qspec, special):
         devk = dev(evk)
         one, many = tf.DeviceBuffer(batch * 2 * level * N), tf.DeviceBuffer(batch * 2 * level * N)
         ctx.rotate(Lk, level, special, devk.ptr, Lk, g, dct.ptr, one.ptr, batch)
-        ctx.rotate_many(Lk, level, special, [devk.ptr], Lk, [g], dct.ptr, many.ptr, batch)
+        if N == 1 << 14:   # (unprepared, tfhe_rotate_many goes through tfhe_rotate there)
+            prep = tf.DeviceBuffer(evk.size)
+            ctx.galois_key_prepare(Lk, Lk, g, devk.ptr, prep.ptr)
+            ctx.rotate_many(Lk, level, special, [prep.ptr], Lk, [g], dct.ptr, many.ptr, batch, prepared=True)
+        else:
+            ctx.rotate_many(Lk, level, special, [devk.ptr], Lk, [g], dct.ptr, many.ptr, batch)
         got = one.to_numpy((batch, 2, level, N))
         assert np.array_equal(got, many.to_numpy((batch, 2, level, N))), g
         pick = [0, batch - 1]

@@ -1490,6 +1490,7 @@ __global__ __launch_bounds__(256) void k_ntt_perm(const u64* __restrict__ src, u
 
 struct ks_arg_t {
     int level, nw, special, polys;
+    u32 rot_g;                   // k_ks_fused SPMODE 3: the Galois element (mod 2N) of a rotation finished in the final store
     limb_sel_t w;                // working limbs: key limbs 0..level-1 (+ special prime)
     tw_t pinv[TFHE_MAX_LIMBS];   // P^-1 mod q_j (special) for j < level: the epilogue of the key sums in tfhe_matmul_diag (ks_keys_t::epi_x)
 };
@@ -2056,7 +2057,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 #endif
     const u32 niter = xcd_limb_niter<TFHE_XCD_KS>(gridDim.x, nitems);
     for (u32 it = 0; it < niter; it++) {
-        const u32 nper = SPMODE == 1 ? 1u : (SPMODE == 2 ? level : nw);   // items per ciphertext
+        const u32 nper = SPMODE == 1 ? 1u : (SPMODE >= 2 ? level : nw);   // items per ciphertext
         const u32 item = xcd_limb_walk<TFHE_XCD_KS>(it, blockIdx.x, gridDim.x, nper, nitems);
         if (item == ~0u) break;
         const u32 b = item / nper, j = SPMODE == 1 ? level : item % nper;
@@ -2117,11 +2118,13 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 #pragma unroll
         for (int sidx = 0; sidx < 2; sidx++) {
             if (sidx) kst(6);
-            if constexpr (SPMODE == 2) {
+            if constexpr (SPMODE >= 2) {   // 3: a rotation finished in the store (ArithFpMDR; KA.rot_g, `ct` the unrotated input)
                 C.md_pinv = (double)KA.pinv[j].w;   // P^-1 mod q_j < 2^52: exact
                 C.md_c = (u32)sidx < add_s ? ct + ((size_t)((b * polys + sidx) * level + j) << LOGB) : zero_row;
+                C.md_g = KA.rot_g;
                 u64* gdst = out + ((size_t)((b * 2 + sidx) * level + j) << LOGB);
-                fused_inv_from_regs<A, LOGB, LOGT, false, (TFHE_TWL_KS & 2) != 0, ArithFpMD>(lds, acc[sidx], gdst, C, tsp + ((size_t)(b * 2 + sidx) << LOGB));
+                typedef typename std::conditional<SPMODE == 3, ArithFpMDR, ArithFpMD>::type AOUT;
+                fused_inv_from_regs<A, LOGB, LOGT, false, (TFHE_TWL_KS & 2) != 0, AOUT>(lds, acc[sidx], gdst, C, tsp + ((size_t)(b * 2 + sidx) << LOGB));
             } else if constexpr (SPMODE == 1) {
                 u64* gdst = out + ((size_t)(b * 2 + sidx) << LOGB);
                 fused_inv_from_regs<A, LOGB, LOGT, false, (TFHE_TWL_KS & 2) != 0>(lds, acc[sidx], gdst, C, nullptr);

@@ -219,6 +219,7 @@ struct ArithFp {
         // ArithFpMD (k_ks_fused, SPMODE 2): P^-1 mod p and the addend row c (or a row of zeros) of the contraction
         double md_pinv = 0.0;
         const u64* md_c = nullptr;
+        u32 md_g = 0;   // ArithFpMDR: the Galois element of a rotation finished in the store
     };
     static TFHE_HD ctx make(const ntt_limb_t& L) {
         return ctx{L.pd, L.pinvd, L.Wd, L.Winvd, L.Wdb, L.Winvdb, L.ninv_d, L.w1inv_ninv_d, L.q};
@@ -311,9 +312,22 @@ struct ArithFpD : ArithFp {
 // through ctx::md_c.  Exact: |reduce(v) - reduce(t)| <= p + 2, the product is <= 0.88 p, plus c < p: 1.9 p into the canonicalisation.
 struct ArithFpMD : ArithFp {
     static constexpr bool moddown = true;
+    static constexpr bool rot = false;
     static TFHE_HD u64 out_moddown(elem v, u64 tsp, u64 cw, const ctx& c) {
         const double x = fp_reduce(v, c.p, c.pinv) - fp_reduce(fp_from_u64(tsp), c.p, c.pinv);
         return fp_canon(fp_mulmod_c(x, ftw_t{c.md_pinv}, c.p, c.pinv) + fp_from_u64(cw), c.p, c.pinv);
+    }
+};
+// ... of a ROTATION whose key sums came from the unrotated digits and the prepared key (hoisting identity): coefficient i goes to
+// position i g mod 2N, negated on a wrap -- before the floor: with v' = -v, t' = P - t (t != 0), c' = -c
+//     (v' - [t']) P^-1 + c' = -((v - t) P^-1 + c) - [t != 0]   (mod p),   since P P^-1 = 1
+// (inv_store scatters the word; same bounds: one more unit into the canonicalisation)
+struct ArithFpMDR : ArithFpMD {
+    static constexpr bool rot = true;
+    static TFHE_HD u64 out_moddown_rot(elem v, u64 tsp, u64 cw, bool neg, const ctx& c) {
+        const double x = fp_reduce(v, c.p, c.pinv) - fp_reduce(fp_from_u64(tsp), c.p, c.pinv);
+        const double y = fp_mulmod_c(x, ftw_t{c.md_pinv}, c.p, c.pinv) + fp_from_u64(cw);
+        return fp_canon(neg ? -y - (tsp != 0 ? 1.0 : 0.0) : y, c.p, c.pinv);
     }
 };
 // The fp64 policy for digit lifts whose SOURCE limb may be above 2^52 (the 60-bit q0 of the reference's CKKS rings next to
@@ -710,16 +724,25 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
                 u64 o[BS];
 #pragma unroll
                 for (int k = 0; k < BS; k++) {
-                    if constexpr (MD) o[k] = A::out_moddown(v[q * BS + k], add[q & 1][k], add2[q & 1][k], C);
-                    else o[k] = SCALE ? A::out_inv_scaled(v[q * BS + k], C) : A::out_inv_lazy(v[q * BS + k], C);
+                    if constexpr (MD) {
+                        if constexpr (A::rot) {   // (whole-transform blocks: N = 2^LOGB)
+                            const int e = q * BS + k, u = e / G::R, r = e % G::R;
+                            const u32 t = ((pos[u] + ((u32)r << G::LO)) * C.md_g) & ((2u << LOGB) - 1u);
+                            o[k] = A::out_moddown_rot(v[q * BS + k], add[q & 1][k], add2[q & 1][k], (t >> LOGB) != 0, C);
+                        } else {
+                            o[k] = A::out_moddown(v[q * BS + k], add[q & 1][k], add2[q & 1][k], C);
+                        }
+                    } else o[k] = SCALE ? A::out_inv_scaled(v[q * BS + k], C) : A::out_inv_lazy(v[q * BS + k], C);
                 }
                 TFHE_SCHED_FENCE();
 #pragma unroll
                 for (int k = 0; k < BS; k++) {
                     const int e = q * BS + k, u = e / G::R, r = e % G::R;
                     if (USEL >= 0 && u != USEL) continue;
-                    if constexpr (MD) gdst[pos[u] + ((u32)r << G::LO)] = o[k];
-                    else gdst[pos[u] + ((u32)r << G::LO)] = addmod(o[k], add[q & 1][k], C.q);
+                    if constexpr (MD) {
+                        if constexpr (A::rot) gdst[((pos[u] + ((u32)r << G::LO)) * C.md_g) & ((1u << LOGB) - 1u)] = o[k];
+                        else gdst[pos[u] + ((u32)r << G::LO)] = o[k];
+                    } else gdst[pos[u] + ((u32)r << G::LO)] = addmod(o[k], add[q & 1][k], C.q);
                 }
                 TFHE_SCHED_FENCE();
             }

@@ -1370,7 +1370,14 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
                 prof_end(c);
                 return TFHE_OK;
             };
-            if (c->logN == 14) {
+            if (c->logN == 14 && g_tail) {   // rotation finished in the second launch's stores (SPMODE 3; `ct` is the unrotated input)
+                constexpr int LOGT = logt_for(14);
+                static bool a14r = false;
+                A.rot_g = (u32)(g_tail & (2 * (u64)c->N - 1));
+                rc = launch2(k_ks_fused<ArithFp, 14, LOGT, false, 1>, k_ks_fused<ArithFp, 14, LOGT, false, 3>, LOGT, fused_lds_bytes<14, LOGT, TFHE_TWL_KS>(), 1u, a14r);
+            } else if (g_tail) {
+                return fail(TFHE_E_UNSUPPORTED, "internal: rotation in the store is an N = 2^14 path");
+            } else if (c->logN == 14) {
                 constexpr int LOGT = logt_for(14);
                 static bool a14 = false;
                 rc = launch2(k_ks_fused<ArithFp, 14, LOGT, false, 1>, k_ks_fused<ArithFp, 14, LOGT, false, 2>, LOGT, fused_lds_bytes<14, LOGT, TFHE_TWL_KS>(), 1u, a14);
@@ -1383,6 +1390,7 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
             HIP_TRY(hipGetLastError());
             return TFHE_OK;
         }
+        if (g_tail) return fail(TFHE_E_UNSUPPORTED, "internal: rotation in the store needs the two-launch special-prime form");
         if (c->logN == 14) {
             constexpr int LOGT = logt_for(14);
             const size_t lds = fused_lds_bytes<14, LOGT, TFHE_TWL_KS>();
@@ -1496,6 +1504,10 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
     // (k_ks_top_tail_rot).  Same bits (the hoisting identity of tfhe_rotate_many).  TFHE_ROT_TAIL=0 keeps the separate pass.
     static const bool rot_tail_on = !(getenv("TFHE_ROT_TAIL") && getenv("TFHE_ROT_TAIL")[0] == '0');
     bool rot_in_tail = rotate && f14 && c->logN >= 15 && rot_tail_on && out != ct && batch >= 8;   // (one (ciphertext, component) per XCD at a time)
+    // N = 2^14 with the special prime (the two-launch fused key switch): the rotation rides on the in-kernel contraction's stores
+    // (k_ks_fused SPMODE 3) -- each workgroup scatters the row it owns
+    static const bool ks_tail_env = getenv("TFHE_KS_TAIL") && getenv("TFHE_KS_TAIL")[0] == '1';
+    if (rotate && f14 && c->logN == 14 && special && !prelifted && !ks_tail_env && rot_tail_on && out != ct) rot_in_tail = true;
     // the same for the N = 2^16 three-kernel path (rings with moduli beyond the fp64 size: the reference's CKKS ring): the key is
     // prepared into the workspace (k_ntt_perm), the rotation rides on k_ks_top_tail_rot<2>
     bool rot_key_prep = false;
