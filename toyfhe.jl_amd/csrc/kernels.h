@@ -1385,6 +1385,43 @@ __global__ __launch_bounds__(256) void k_rescale(const u64* __restrict__ src, u6
     }
 }
 
+// The same, coefficient-major (r04): a thread takes two coefficients of ONE polynomial through all its limbs, so the last limb's
+// words are read once -- row by row (above) the blocks of the nl - 1 output rows of a polynomial run on different XCDs and each
+// fetched the last limb for itself: 2.3-2.5 x the algorithmic bytes at an HBM-bound kernel (profiles/r04v_pmc_configs.txt).
+__global__ __launch_bounds__(256) void k_rescale_cm(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                     const ntt_limb_t* __restrict__ LT, limb_sel_t sel, rescale_arg_t ra,
+                                                     u32 n) {
+    const u32 nl = (u32)sel.n, p = blockIdx.x;
+    const u64* sp = src + (size_t)p * nl * n;
+    u64* dp = dst + (size_t)p * (nl - 1) * n;
+    for (u32 i = (blockIdx.y * blockDim.x + threadIdx.x) * 2u; i < n; i += gridDim.y * blockDim.x * 2u) {
+        const u64x2_t l = *(const u64x2_t*)(sp + (size_t)(nl - 1) * n + i);
+        // the limbs in blocks of JB: every word of a block is requested before the first is used (one limb at a time the loop ran at
+        // the latency of its loads)
+        constexpr u32 JB = 8;
+        for (u32 j0 = 0; j0 + 1 < nl; j0 += JB) {
+            u64x2_t cj[JB];
+#pragma unroll
+            for (u32 t = 0; t < JB; t++) {
+                const u32 j = j0 + t + 1 < nl ? j0 + t : nl - 2;
+                cj[t] = *(const u64x2_t*)(sp + (size_t)j * n + i);
+            }
+#pragma unroll
+            for (u32 t = 0; t < JB; t++) {
+                const u32 j = j0 + t;
+                if (j + 1 < nl) {
+                    const ntt_limb_t& L = LT[sel.idx[j]];
+                    const u64 q = L.q;
+                    u64x2_t o;
+                    o.x = shoup_full(submod(cj[t].x, barrett_reduce128(l.x, 0, L.br), q), ra.qlinv[j], q);
+                    o.y = shoup_full(submod(cj[t].y, barrett_reduce128(l.y, 0, L.br), q), ra.qlinv[j], q);
+                    *(u64x2_t*)(dp + (size_t)j * n + i) = o;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_select(const u64* __restrict__ src, u64* __restrict__ dst, limb_sel_t which,
                                                  int src_limbs, u32 n) {
     const u32 row = blockIdx.x, j = row % (u32)which.n, p = row / (u32)which.n;

@@ -971,6 +971,13 @@ static int do_rescale(tfhe_ctx* c, const u64* src, u64* dst, int64_t count, cons
         ra.qlinv[j] = hostmath::make_tw(hostmath::invmod_prime(ql % qj, qj), qj);
     }
     if (count == 0) return TFHE_OK;
+    static const bool row_major = getenv("TFHE_RESCALE_ROWS") && getenv("TFHE_RESCALE_ROWS")[0] == '1';
+    if (!row_major && c->N >= 512 && (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {   // coefficient-major: the last limb read once per polynomial
+        const unsigned want = (unsigned)((2048 + count - 1) / count), cap = (unsigned)(c->N / 512);
+        hipLaunchKernelGGL(k_rescale_cm, dim3((unsigned)count, std::max(1u, std::min(want, cap))), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, ra, (u32)c->N);
+        HIP_TRY(hipGetLastError());
+        return TFHE_OK;
+    }
     hipLaunchKernelGGL(k_rescale, row_grid((unsigned)(count * (sel.n - 1)), (size_t)c->N), dim3(256), 0, c->stream, src, dst, c->limbs_dev, sel, ra, (u32)c->N);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
