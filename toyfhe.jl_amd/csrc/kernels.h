@@ -2802,25 +2802,38 @@ __global__ __launch_bounds__(256) void k_ks_top_tail_rot(const u64* __restrict__
 #pragma unroll
                 for (int r = 0; r < R; r++) p[r] = neg[r] ? negmod(p[r], LP.q) : p[r];   // the rotated polynomial's unsigned representative
             }
-            for (u32 j = team; j < level; j += teams) {
-                const ntt_limb_t& L = LT[A.w.idx[j]];
-                const u64 q = L.q;
-                const u64* tj = T + ((size_t)pr * A.nw + j) * n;
-                const u64* c = s < add_s ? ct + (((size_t)b * A.polys + s) * level + j) * n : nullptr;
-                u64* o = out + ((size_t)pr * level + j) * n;
-                u64 v[R];
+            // the team's limbs in blocks of JB: every word of a block is requested before the first is used
+            constexpr u32 JB = X == 1 ? 4 : 2;
+            const bool addc = s < add_s;
+            for (u32 j0 = team; j0 < level; j0 += teams * JB) {
+                u64 v[JB][R], cv[JB][R];
 #pragma unroll
-                for (int r = 0; r < R; r++) v[r] = tj[k + (u32)r * stride];
-                ntt_inv_top_regs<X>(v, L);
+                for (u32 t = 0; t < JB; t++) {
+                    const u32 j = j0 + t * teams < level ? j0 + t * teams : j0;
+                    const u64* tj = T + ((size_t)pr * A.nw + j) * n;
+                    const u64* c = ct + (((size_t)b * A.polys + (addc ? s : 0u)) * level + j) * n;
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    u64 x = neg[r] ? negmod(v[r], q) : v[r];
-                    if (A.special) x = shoup_full(submod(x, barrett_reduce128(p[r], 0, L.br), q), ra.qlinv[j], q);
-                    if (c) {
-                        const u64 cv = c[k + (u32)r * stride];
-                        x = addmod(x, neg[r] ? negmod(cv, q) : cv, q);
+                    for (int r = 0; r < R; r++) {
+                        v[t][r] = tj[k + (u32)r * stride];
+                        cv[t][r] = addc ? c[k + (u32)r * stride] : 0;
                     }
-                    o[m[r]] = x;
+                }
+#pragma unroll
+                for (u32 t = 0; t < JB; t++) {
+                    const u32 j = j0 + t * teams;
+                    if (j < level) {
+                        const ntt_limb_t& L = LT[A.w.idx[j]];
+                        const u64 q = L.q;
+                        u64* o = out + ((size_t)pr * level + j) * n;
+                        ntt_inv_top_regs<X>(v[t], L);
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            u64 x = neg[r] ? negmod(v[t][r], q) : v[t][r];
+                            if (A.special) x = shoup_full(submod(x, barrett_reduce128(p[r], 0, L.br), q), ra.qlinv[j], q);
+                            if (addc) x = addmod(x, neg[r] ? negmod(cv[t][r], q) : cv[t][r], q);
+                            o[m[r]] = x;
+                        }
+                    }
                 }
             }
         }
