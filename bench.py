@@ -109,6 +109,127 @@ def source_id():
     return h.hexdigest()[:16]
 
 
+# ---- the stdout line: compact (the driver's capture is ~9.6 KB; BENCH_r04 lost a 22.8 KB line), the full record goes to a file -----
+LINE_LIMIT = 4096
+FULL_RECORD = os.path.join(ROOT, "profiles", "bench_full.json")
+
+
+def _r(x, sig=5):
+    """floats to `sig` significant digits (the line is a summary; the full record keeps every digit)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _compact_roofline(roof):
+    keep = ("bound", "achieved", "peak", "unit", "frac", "essential_frac", "hbm_frac", "ctmul_hbm_frac", "traffic",
+            "traffic_per_ctmul_over_algorithmic", "avg_launch_ms", "launches", "pmc_source_id", "pmc_stale")
+    out = {k: roof.get(k) for k in keep if k in roof}
+    out["kernel"] = str(roof.get("kernel", "")).split(":")[0]
+    if "ctmul_algorithmic_bytes" in roof:
+        out["algorithmic_bytes"] = roof["ctmul_algorithmic_bytes"]
+    if "traffic_per_ctmul_over_algorithmic" in out:
+        out["traffic_over_algorithmic"] = out.pop("traffic_per_ctmul_over_algorithmic")
+    te = roof.get("transform_equiv") or {}
+    if te:
+        out["transform_equiv_GBs"] = te.get("achieved")
+    return out
+
+
+def _compact_config(c):
+    """one short dict per other_configs / configs_multi record: name, rates, dominant kernel, its fraction and traffic ratio"""
+    name = str(c.get("config", "?"))
+    out = {"name": name.split(" (")[0][:44]}
+    if "circuit" in c:
+        out["name"] = ("MNIST 2^16 " if c.get("N") == 65536 else f"MNIST N={c.get('N')} ") + \
+            ("restructured (63 keys, hoisted)" if str(c["circuit"]).startswith("restructured") else "reference-shaped (1 key, chained)")
+    for src, dst in (("keyswitch_per_s", "ks_s"), ("rotate_per_s", "rot_s"), ("rescale_ct_per_s", "resc_s"), ("fwd_GBs", "fwd_GBs"),
+                     ("inv_GBs", "inv_GBs"), ("images_per_s", "img_s"), ("ms_per_pass", "ms_pass"), ("value", "value"), ("unit", "unit"),
+                     ("ms_per_step", "ms_step"), ("nranks_seen", "nranks_seen"), ("imbalance_max_over_min", "imbalance"), ("global_units", "units"), ("scaling", "scaling"),
+                     ("batch", "batch"), ("oracle_checked", "ok"), ("error", "error")):
+        if src in c and c[src] is not None:
+            out[dst] = c[src] if not isinstance(c[src], str) else c[src][:40]
+    roof = c.get("roofline") or {}
+    for op in ("keyswitch", "nntt", "inntt", "pass"):                 # the dominant kernel of the case's main operation
+        r = roof.get(op)
+        if r:
+            out.setdefault("kern", {})[op] = [str(r.get("kernel", "")).replace(" ", "")[:36], r.get("bound"), _r(r.get("frac"), 3),
+                                              _r(r.get("traffic_over_algorithmic"), 3)]          # kernel, bound, frac, traffic / algorithmic
+    if (c.get("roofline_source") or {}).get("pmc_stale"):
+        out["pmc_stale"] = True
+    return out
+
+
+def compact_line(result, limit=LINE_LIMIT):
+    """The ONE stdout line of a run, built from the full record: every key of the bench contract, `roofline` and `cpu_baseline`,
+    a short `ntt` record and one short dict per other configuration.  Guaranteed to serialise below `limit` bytes: optional parts
+    are dropped in a fixed order (per-config kernel notes, then the configs' secondary rates) until it fits."""
+    line = {k: result[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data") if k in result}
+    for k in ("ms_per_step_median", "nranks_seen", "imbalance_max_over_min", "global_units", "algorithmic_GBs", "frac_of_hbm_peak_per_gpu", "oracle_checked"):
+        if k in result:
+            line[k] = result[k] if not isinstance(result[k], str) else result[k][:60]
+    cfg = dict(result.get("config") or {})
+    if isinstance(cfg.get("workload"), str):
+        cfg["workload"] = cfg["workload"][:160]
+    line["config"] = cfg
+    if "roofline" in result:
+        line["roofline"] = _compact_roofline(result["roofline"]) if "transform_equiv" in result["roofline"] or "essential_note" in result["roofline"] \
+            else {k: (v if not isinstance(v, str) else v[:80]) for k, v in result["roofline"].items() if not isinstance(v, (dict, list))}
+    cb = result.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": str(cb.get("sample", ""))[:120]}
+        if cb.get("single_thread"):
+            line["cpu_baseline"]["single_thread"] = {"value": cb["single_thread"].get("value"), "cores": 1}
+    nt = result.get("ntt")
+    if nt:
+        line["ntt"] = {"fwd_GBs": nt.get("fwd_GBs"), "inv_GBs": nt.get("inv_GBs"), "fwd_frac": nt.get("fwd_frac_of_hbm_peak"),
+                       "inv_frac": nt.get("inv_frac_of_hbm_peak"), "peak_GBs": nt.get("peak_GBs")}
+    g = result.get("gather")
+    if g:
+        line["gather"] = {k: (v if not isinstance(v, str) else v[:80]) for k, v in g.items()
+                          if k in ("collective", "ms_per_step", "ms", "GBs_per_rank", "value_with_gather", "error", "fallback")}
+    if result.get("cabi_gather_error"):                              # tfhe_comm_create / tfhe_gather failed: torch's collective ran instead
+        line.setdefault("gather", {})["fallback"] = str(result["cabi_gather_error"])[:120]
+    for key in ("other_configs", "configs_multi"):
+        if result.get(key):
+            line[key] = [_compact_config(c) for c in result[key]]
+    if result.get("errors"):
+        line["errors"] = [str(e)[:120] for e in result["errors"]][:4]
+    line["full_record"] = os.path.relpath(FULL_RECORD, ROOT)
+    line = _r(line)
+    shrink = [lambda: [c.pop("kern", None) for k in ("other_configs", "configs_multi") for c in line.get(k, [])],
+              lambda: [c.pop(f, None) for k in ("other_configs", "configs_multi") for c in line.get(k, []) for f in ("resc_s", "batch", "ms_pass", "ok")],
+              lambda: line.pop("other_configs", None), lambda: line.pop("configs_multi", None), lambda: line.pop("gather", None),
+              lambda: line.pop("errors", None), lambda: line.pop("ntt", None)]
+    for step in shrink:
+        if len(json.dumps(line)) < limit:
+            break
+        step()
+    return line
+
+
+def emit(result):
+    """full record -> profiles/bench_full.json (+ gpurun_out/ when present) and stderr; compact line -> the LAST stdout line"""
+    full = json.dumps(result)
+    for path in (FULL_RECORD, os.path.join(ROOT, "gpurun_out", "bench_full.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(full + "\n")
+        except OSError:
+            pass
+    print(full, file=sys.stderr, flush=True)
+    print(json.dumps(compact_line(result)), flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -149,7 +270,11 @@ def main():
                     "scaling": rec.get("scaling"), "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                     "config": {"workload": rec["config"], "global_units": rec.get("global_units"), "sharding": f"units x{world}, no data-path collective"}}
             line.update({k: v for k, v in rec.items() if k not in line and k != "config"})
-            print(json.dumps(line))
+            if rec.get("algorithmic_GBs") is not None:                  # SURVEY 8(d) bytes of a key switch (4 level N 8) x rate, per GPU, against HBM
+                line["roofline"] = {"bound": "hbm", "achieved": rec["algorithmic_GBs"] / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": rec["algorithmic_GBs"] / world / HBM_PEAK_GBS, "traffic": None,
+                                    "note": "algorithmic bytes per GPU; counters per kernel: profiles/pmc_configs.json"}
+            emit(line)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -213,15 +338,24 @@ def main():
       try:                                                              # never let the optional leg cost the headline line
           import torch.distributed as dist
           flat = out.view(-1)
-          comm = None
+          comm, fallback, run_gather = None, None, None
+          if args.backend == "nccl":
+              full = torch.empty(world * flat.numel(), dtype=flat.dtype, device=dev)
           if args.backend == "nccl" and args.cabi_gather:
-              full = torch.empty(world * flat.numel(), dtype=flat.dtype, device=dev)
-              comm = tdist.make_comm()                                   # tfhe_comm_create over the same ranks
-              run_gather = lambda: comm.gather(ctx, flat.data_ptr(), full.data_ptr(), flat.numel())
-          elif args.backend == "nccl":
-              full = torch.empty(world * flat.numel(), dtype=flat.dtype, device=dev)
+              try:                                                       # the library's own communicator; a failure is a one-line reason, not a lost leg
+                  comm = tdist.make_comm()                               # tfhe_comm_create over the same ranks
+                  run_gather = lambda: comm.gather(ctx, flat.data_ptr(), full.data_ptr(), flat.numel())
+                  run_gather()
+                  torch.cuda.synchronize()
+              except Exception as e:                                     # noqa: BLE001
+                  comm, run_gather, fallback = None, None, f"tfhe_comm_create / tfhe_gather: {type(e).__name__}: {e}"[:160]
+              # every rank must take the same branch: one rank's failure sends all to torch's collective
+              ok_all = tdist.max_over_ranks(0.0 if comm is not None else 1.0, device=coll_dev) == 0.0
+              if not ok_all and comm is not None:
+                  comm, run_gather, fallback = None, None, "tfhe_comm_create failed on another rank"
+          if run_gather is None and args.backend == "nccl":
               run_gather = lambda: dist.all_gather_into_tensor(full, flat)
-          else:
+          elif run_gather is None:
               run_gather = lambda: tdist.gather_results(out[:8].cpu())    # functional check only
           run_gather()
           torch.cuda.synchronize(); tdist.barrier()
@@ -236,6 +370,8 @@ def main():
                     if args.backend == "nccl" else f"{args.backend} functional check",
                     "ms_per_step": g_s * 1e3, "bytes_received_per_rank": gbytes, "GBs_per_rank": gbytes / g_s / 1e9,
                     "value_with_gather": B * world / (elapsed / args.steps + g_s)}
+          if fallback:
+              gather["fallback"] = fallback
           if args.backend == "nccl":
               del full
       except Exception as e:                                          # noqa: BLE001
@@ -427,7 +563,7 @@ def main():
             except Exception as e:                                      # noqa: BLE001
                 result.setdefault("errors", []).append(f"{leg.__name__}: {type(e).__name__}: {e}")
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
     if world > 1:
         torch.distributed.destroy_process_group()
 

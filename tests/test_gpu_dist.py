@@ -115,6 +115,16 @@ def test_cabi_gather_world_of_one():
     comm.close()
 
 
+def _line_and_record(out):
+    """bench.py prints ONE compact line on stdout (the driver parses it; < 4 KB) and the full record on stderr + profiles/bench_full.json"""
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[-1]) < 4096, [len(l) for l in lines]
+    line = json.loads(lines[-1])
+    full = json.loads([l for l in out.stderr.splitlines() if l.startswith('{"metric"')][-1])
+    assert json.load(open(os.path.join(ROOT, line["full_record"]))) == full
+    return line, full
+
+
 def test_bench_spawns_the_ranks_it_is_asked_for():
     """`python bench.py --gpus 2` outside torchrun launches two ranks itself and reports n_gpus = 2 with the whole-job
     rate (one GPU each over RCCL when two are visible; otherwise both on GPU 0 over gloo as a functional check)."""
@@ -125,7 +135,10 @@ def test_bench_spawns_the_ranks_it_is_asked_for():
            "--no-cpu", "--no-ntt", "--backend", backend, "--total", "96"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    line, res = _line_and_record(out)
+    assert line["n_gpus"] == 2 and line["nranks_seen"] == 2 and line["config"]["global_batch"] == 128 and line["value"] > 0
+    assert line["scaling"] == "weak" and line["gather"]["value_with_gather"] <= line["value"] * 1.0001 and "roofline" in line
+    assert {m["name"][:5] for m in line["configs_multi"]} == {"cfg#4", "cfg#5"} and all(m["nranks_seen"] == 2 and m["value"] > 0 for m in line["configs_multi"])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 128 and res["value"] > 0
     assert res["scaling"] == "weak" and "gather" in res and res["gather"]["value_with_gather"] <= res["value"] * 1.0001
     # the configurations BASELINE.json defines across the GPUs of a node ride in the same line (here scaled down by --total)
@@ -150,8 +163,9 @@ def test_bench_multi_rank_modes_of_the_other_configurations(cfg, total, units):
            "--total", str(total), "--backend", backend]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    line, res = _line_and_record(out)
     assert "error" not in res, res
+    assert line["n_gpus"] == 2 and line["nranks_seen"] == 2 and line["value"] > 0 and line["roofline"]["bound"] == "hbm" and line["scaling"] == res["scaling"]
     assert res["n_gpus"] == 2 and res["nranks_seen"] == 2 and res["value"] > 0 and res["steps"] == 2 and res["warmup"] == 1
     key = "sets" if cfg == "cfg5" else "units"
     assert [r[key] for r in res["per_rank"]] == units
