@@ -274,6 +274,9 @@ def main():
                 line["roofline"] = {"bound": "hbm", "achieved": rec["algorithmic_GBs"] / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": rec["algorithmic_GBs"] / world / HBM_PEAK_GBS, "traffic": None,
                                     "note": "algorithmic bytes per GPU; counters per kernel: profiles/pmc_configs.json"}
+            else:                                                       # cfg#5 (the MNIST pass: ~30 kernels): no single launch to price
+                line["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                    "note": "a pass of ~500 launches; per-kernel counters: profiles/pmc_configs.json (MNIST case)"}
             emit(line)
         if world > 1:
             torch.distributed.destroy_process_group()

@@ -166,6 +166,7 @@ def test_bench_multi_rank_modes_of_the_other_configurations(cfg, total, units):
     line, res = _line_and_record(out)
     assert "error" not in res, res
     assert line["n_gpus"] == 2 and line["nranks_seen"] == 2 and line["value"] > 0 and line["roofline"]["bound"] == "hbm" and line["scaling"] == res["scaling"]
+    assert (line["roofline"]["frac"] is not None) == (cfg != "cfg5")
     assert res["n_gpus"] == 2 and res["nranks_seen"] == 2 and res["value"] > 0 and res["steps"] == 2 and res["warmup"] == 1
     key = "sets" if cfg == "cfg5" else "units"
     assert [r[key] for r in res["per_rank"]] == units

@@ -124,6 +124,7 @@ get get! haskey all isempty push! map tuple length size axes zeros zero collect 
 enumerate fieldtypes round ispow2 trailing_zeros ndigits numerator denominator big invoke typeof eltype isa new similar string
 Ref Dict IdDict Vector Matrix UInt64 UInt32 Int32 Int64 Cint Float64 ComplexF64 Rational BigInt AssertionError OutOfMemoryError
 OffsetArray StructArray Ptr in ccall tuple first last min max setindex! getindex sel x HipVector Int
+ReentrantLock lock empty! parse pop! popfirst!
 """.split())
 
 

@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cstdlib>
 #include <deque>
 #include <map>
@@ -205,13 +207,21 @@ inline hipError_t alloc(size_t bytes, void** out) {
         // allocating -- the host stays ahead of the device by the blocks it already owns, not by ever more memory.
         free_stale_ready_locked(s, d);
         if (d.cached_bytes > d.soft_cached) {
-            std::vector<hipEvent_t> evs;
-            for (const parked_t& b : d.parked)
-                if (b.p && b.bytes == bytes) { evs = b.evs; break; }
-            if (!evs.empty()) {
-                g.unlock();                                      // release() on other threads must not wait behind this
-                for (hipEvent_t ev : evs)
-                    if (hipEventSynchronize(ev) != hipSuccess) (void)hipGetLastError();
+            // Wait by POLLING under the lock (r05): the events of a parked block belong to the tables -- poll_locked on
+            // another thread may return them to the pool and release() re-record them on a busy stream while this thread is
+            // unlocked, so synchronising on copied handles could block on unrelated later work.  Between polls the mutex is free
+            // (release() on finalizer threads never waits behind this); the loop ends when a block of this size is ready or none
+            // of this size is parked any more (a trim on another thread).
+            for (unsigned spin = 0;; spin++) {
+                it = d.ready.find(bytes);
+                if (it != d.ready.end() && !it->second.empty()) break;
+                bool parked_one = false;
+                for (const parked_t& b : d.parked)
+                    if (b.p && b.bytes == bytes) { parked_one = true; break; }
+                if (!parked_one) break;
+                g.unlock();
+                if (spin < 256) std::this_thread::yield();
+                else std::this_thread::sleep_for(std::chrono::microseconds(20));
                 g.lock();
                 poll_locked(d);
             }

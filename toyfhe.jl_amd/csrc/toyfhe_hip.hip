@@ -88,14 +88,19 @@ namespace {
 int ensure_ws(tfhe_ctx* c, size_t bytes, void** out, bool pooled = false) {
     if (bytes > c->ws_bytes) {
         if (c->ws) {
-            if (c->ws_pooled) {
-                HIP_TRY(devalloc::release(c->ws));               // parked behind events on every context stream: no wait
-            } else {
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                HIP_TRY(hipFree(c->ws));
-            }
+            // the slot is cleared BEFORE anything can return (r05, ADVICE r04: devalloc::release erases the block from its live
+            // table even when it reports an error -- a context left pointing at it would hand a stale pointer to the next free)
+            void* old = c->ws;
+            const bool old_pooled = c->ws_pooled;
             c->ws = nullptr;
             c->ws_bytes = 0;
+            c->ws_pooled = false;
+            if (old_pooled) {
+                HIP_TRY(devalloc::release(old));                 // parked behind events on every context stream: no wait
+            } else {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                HIP_TRY(hipFree(old));
+            }
         }
         size_t got = bytes;
         hipError_t e = pooled ? devalloc::alloc_ws(bytes, c->stream, &c->ws, &got) : devalloc::malloc_retry(&c->ws, bytes);
@@ -1510,15 +1515,19 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
     // it is converted (k_evk_to_f64), the key sums are those of the unrotated digits, the automorphism rides on the tail's stores
     // (k_ks_top_tail_rot).  Same bits (the hoisting identity of tfhe_rotate_many).  TFHE_ROT_TAIL=0 keeps the separate pass.
     static const bool rot_tail_on = !(getenv("TFHE_ROT_TAIL") && getenv("TFHE_ROT_TAIL")[0] == '0');
-    bool rot_in_tail = rotate && f14 && c->logN >= 15 && rot_tail_on && out != ct && batch >= 8;   // (one (ciphertext, component) per XCD at a time)
+    // The tail scatters into `out` while other workgroups still read the unrotated `ct`: the two RANGES must be disjoint (r05, ADVICE
+    // r04: pointer inequality let a partially overlapping out / ct race) -- otherwise the rotated-copy path below runs.
+    const bool io_disjoint = (const char*)(out + (size_t)batch * 2 * level * N) <= (const char*)ct ||
+                             (const char*)(ct + (size_t)batch * polys * level * N) <= (const char*)out;
+    bool rot_in_tail = rotate && f14 && c->logN >= 15 && rot_tail_on && io_disjoint && batch >= 8;   // (one (ciphertext, component) per XCD at a time)
     // N = 2^14 with the special prime (the two-launch fused key switch): the rotation rides on the in-kernel contraction's stores
     // (k_ks_fused SPMODE 3) -- each workgroup scatters the row it owns
     static const bool ks_tail_env = getenv("TFHE_KS_TAIL") && getenv("TFHE_KS_TAIL")[0] == '1';
-    if (rotate && f14 && c->logN == 14 && special && !prelifted && !ks_tail_env && rot_tail_on && out != ct) rot_in_tail = true;
+    if (rotate && f14 && c->logN == 14 && special && !prelifted && !ks_tail_env && rot_tail_on && io_disjoint) rot_in_tail = true;
     // the same for the N = 2^16 three-kernel path (rings with moduli beyond the fp64 size: the reference's CKKS ring): the key is
     // prepared into the workspace (k_ntt_perm), the rotation rides on k_ks_top_tail_rot<2>
     bool rot_key_prep = false;
-    if (rotate && !f14 && rot_tail_on && out != ct && batch >= 8) {
+    if (rotate && !f14 && rot_tail_on && io_disjoint && batch >= 8) {
         ks_arg_t KA;
         memset(&KA, 0, sizeof KA);
         KA.level = level; KA.nw = nw;
@@ -1738,22 +1747,31 @@ int tfhe_matmul_diag(tfhe_ctx* c, int Lk, int level, int special, const uint64_t
     {
         // (hipMemGetInfo is a driver round trip -- milliseconds in a process with many allocations -- and this call sits in the
         // launch path of a host-bound circuit: the reading is kept for two seconds)
+        // (r05, ADVICE r04: the reading and the allocator's cached bytes are those of THIS context's device -- a process driving
+        // several GPUs computed the cap from whichever device had asked last and from the cache summed over all of them)
+        struct mi_t { size_t free_bytes = 0; std::chrono::steady_clock::time_point at{}; };
         static std::mutex mi_mu;
-        static size_t mi_free = 0;
-        static std::chrono::steady_clock::time_point mi_at{};
+        static std::map<int, mi_t> mi_dev;
         size_t fr = 0, tot = 0;
         bool have = false;
+        const int cur_dev = devalloc::current_device();          // what hipMemGetInfo reads and where the workspace will be allocated
         {
             std::lock_guard<std::mutex> g(mi_mu);
+            mi_t& mi = mi_dev[cur_dev];
             const auto now = std::chrono::steady_clock::now();
-            if (mi_free && now - mi_at < std::chrono::seconds(2)) { fr = mi_free; have = true; }
-            else if (hipMemGetInfo(&fr, &tot) == hipSuccess) { mi_free = fr; mi_at = now; have = true; }
+            if (mi.free_bytes && now - mi.at < std::chrono::seconds(2)) { fr = mi.free_bytes; have = true; }
+            else if (hipMemGetInfo(&fr, &tot) == hipSuccess) { mi.free_bytes = fr; mi.at = now; have = true; }
             else (void)hipGetLastError();
         }
         if (have) {
-            uint64_t cached = 0;
-            tfhe_alloc_stats(nullptr, &cached, nullptr, nullptr);
-            ws_cap = std::min(ws_cap, std::max<size_t>((fr + c->ws_bytes + (size_t)cached) / 2, (size_t)1 << 30));
+            size_t cached = 0;
+            {
+                devalloc::state_t& as = devalloc::S();
+                std::lock_guard<std::mutex> g(as.mu);
+                auto it = as.devs.find(cur_dev);
+                if (it != as.devs.end()) cached = it->second.cached_bytes;
+            }
+            ws_cap = std::min(ws_cap, std::max<size_t>((fr + c->ws_bytes + cached) / 2, (size_t)1 << 30));
         }
     }
     int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({batch, (int64_t)512, (int64_t)(ws_cap / per_ct)}));

@@ -43,7 +43,9 @@ function check(rc::Cint)
     rc == -1 && throw(AssertionError(msg))              # pow2_cyc_rings.jl:31,61,116; rlwe_she.jl:318
     rc in (-3, -4) && throw(ToyFHE.UsageError(msg))     # rlwe_she.jl:223-225,233-235,248-250
     rc == -7 && error(msg)                              # crt.jl:270,274
-    rc == -5 && throw(OutOfMemoryError())
+    if rc == -5                                         # TFHE_E_NOMEM: give the key caches back before the caller sees it (a retry may fit)
+        release_key_caches!(); throw(OutOfMemoryError())
+    end
     error("HIP: " * msg)
 end
 
@@ -312,28 +314,54 @@ end
 pack(ctx::HipRing, c::CipherText{Enc,P,<:RingElement{ℛ,T}}) where {Enc,P,ℛ,T} =
     pack(ctx, HipVector[coeffs_primal(x).parent for x in c.cs], T)
 # evaluation key: [digit][mask, masked][Lk][N], NTT domain (rlwe_she.jl:297, 340-344), packed once per key (one polynomial each)
+# Both key caches are guarded by one lock (rotate_many / matmul_diag may run from several tasks; get! on an IdDict is not
+# task-safe) and can be given back: release_key_caches!() empties them (the HipVector finalizers tfhe_free the buffers), and
+# `check` calls it once before reporting an out-of-memory error, so the copies are not invisible to the allocator's retry.
+const KEY_LOCK = ReentrantLock()
 const PACKED_KEYS = IdDict{Any,HipVector}()
 function pack(ek::KeySwitchKey)
-    get!(PACKED_KEYS, ek) do
-        ℛk = NTT.ring(ek.key[1].mask); parts = HipVector[]
-        for kc in ek.key
-            push!(parts, coeffs_dual(kc.mask).parent); push!(parts, coeffs_dual(kc.masked).parent)
+    lock(KEY_LOCK) do
+        get!(PACKED_KEYS, ek) do
+            ℛk = NTT.ring(ek.key[1].mask); parts = HipVector[]
+            for kc in ek.key
+                push!(parts, coeffs_dual(kc.mask).parent); push!(parts, coeffs_dual(kc.masked).parent)
+            end
+            pack(hipring(ℛk), parts, eltype(ℛk))
         end
-        pack(hipring(ℛk), parts, eltype(ℛk))
     end
 end
 # Galois keys PREPARED for the hoisted rotations (tfhe_rotate_many with prepared = 1, tfhe_matmul_diag): every NTT-domain row
 # permuted by g^-1 (tfhe_galois_key_prepare), once per key -- what GaloisKey.prepared() is in the Python mirror.
+# The prepared copy is a SECOND full device copy of the key (2.8 GB more for 63 rotations at N = 2^16): the cache is bounded
+# (TOYFHE_HIP_PREPARED_GIB, default 8) and evicts in insertion order; an evicted key is prepared again from the packed one on its
+# next use (one permutation pass).  Callers hold the returned vectors for the duration of their ccall, so eviction never frees
+# a buffer in use.
 const PREPARED_KEYS = IdDict{Any,HipVector}()
+const PREPARED_ORDER = Any[]
+const PREPARED_BYTES = Ref{Int}(0)
+prepared_limit() = round(Int, parse(Float64, get(ENV, "TOYFHE_HIP_PREPARED_GIB", "8")) * 2.0^30)
 function prepared(gk::ToyFHE.GaloisKey)
-    get!(PREPARED_KEYS, gk) do
+    lock(KEY_LOCK) do
+        haskey(PREPARED_KEYS, gk) && return PREPARED_KEYS[gk]
         ek = gk.key; key = pack(ek); keyring = NTT.ring(ek.key[1].mask); ctx = hipring(keyring)
         out = HipVector{eltype(keyring)}(key.limbs, key.n, key.count); on(ctx, (out,), (key,))
         GC.@preserve key out check(ccall((:tfhe_galois_key_prepare, lib), Cint,
                     (Ptr{Cvoid}, Cint, Cint, UInt64, Ptr{UInt64}, Ptr{UInt64}),
                     ctx.handle, nlimbs(eltype(keyring)), length(ek.key), gk.galois_element, key.ptr, out.ptr))
+        PREPARED_KEYS[gk] = out; push!(PREPARED_ORDER, gk); PREPARED_BYTES[] += 8 * allwords(out)
+        while PREPARED_BYTES[] > prepared_limit() && length(PREPARED_ORDER) > 1
+            old = popfirst!(PREPARED_ORDER); v = pop!(PREPARED_KEYS, old); PREPARED_BYTES[] -= 8 * allwords(v)
+        end
         out
     end
+end
+function release_key_caches!()
+    lock(KEY_LOCK) do
+        empty!(PACKED_KEYS); empty!(PREPARED_KEYS); empty!(PREPARED_ORDER); PREPARED_BYTES[] = 0
+    end
+    GC.gc(false)                                       # run the HipVector finalizers (tfhe_free: parked, then reusable)
+    ccall((:tfhe_alloc_trim, lib), Cint, ())
+    nothing
 end
 # unpack: `polys` (batched) ring elements of ℛ from a packed [count][polys][limbs][N] buffer; dual = true: NTT-domain results
 function unpack(ctx::HipRing, buf::HipVector, ℛ, polys::Integer; dual::Bool=false)
