@@ -35,13 +35,27 @@ struct limb_sel_t {  // which context modulus each buffer limb uses (crtselect, 
 // limb j of polynomial `poly`; x = log2(N) - LOGB (0 when the whole limb fits one LDS block).
 // ------------------------------------------------------------------------------------------------
 
+// Early LDS stores (ntt_core.h, fwd_compute / inv_compute `lds_early`), per kernel family: bit set = the pass writes its results to
+// LDS from inside its last butterfly stage.  Measured per site (r05, profiles/LOG.md; registers from the ISA):
+//   bit 0  k_ntt_fwd_quad middle pass     182 -> 234 VGPRs, no scratch: N = 2^16 forward 2.75 -> 3.00 TB/s (mixed ring 2.00 -> 2.12)   ON
+//   bit 5  k_ntt_inv_staged middle pass   140 -> 166 VGPRs: inverse at 2^14 + 0.7 %                                                     ON
+//   bit 7  k_ntt_inv_pair middle pass     scratch 164 -> 96 bytes                                                                       ON
+//   bit 11 k_ntt_fwd_pf middle pass       234 -> 238 VGPRs: no change (3.93 / 3.95 TB/s)                                                off
+//   bit 3  fwd_schedule (block kernels)   u64 forward 117 -> 188 VGPRs: 60-bit transforms 2.06 -> 1.91 TB/s                              off
+//   bits 1, 2, 6, 9, 10 (quad first pass, k_ntt_fwd_pair, inv_schedule, k_ntt_inv_quad2, k_ntt_fwd_pf first pass): 80 - 830 bytes of scratch  off
+// The fused kernels sit at the 256-VGPR cap: the same change spills 13-20 accumulator registers per digit there (headline 61.2 k ->
+// 56.4 k ciphertext-mul/s, cfg#3 40.1 k -> 30.4 k key switches/s) -- they keep the store phase behind the pass.
+#ifndef TFHE_ES_SITES
+#define TFHE_ES_SITES 0x0a1
+#endif
+#define TFHE_ES(bit) (((TFHE_ES_SITES) >> (bit)) & 1)
 // ---- simple schedule: one workgroup per item, passes separated by barriers ----
 template <class A, int LOGB, int LOGT, int S0>
 __device__ __forceinline__ void fwd_schedule(u64* lds, const u64* gsrc, u64* gdst, const typename A::ctx& C, u32 tid,
                                              u32 pre, int x, u32 sbrev, const lift_t* lift) {
     constexpr int K = pass_k_fwd(LOGB, LOGT, S0);
     constexpr bool LAST = (S0 + K == LOGB);
-    ntt_fwd_pass<A, LOGB, LOGT, S0, K, S0 == 0, LAST>(lds, gsrc, gdst, C, tid, pre, x, sbrev, lift);
+    ntt_fwd_pass<A, LOGB, LOGT, S0, K, S0 == 0, LAST, TFHE_ES(3) != 0>(lds, gsrc, gdst, C, tid, pre, x, sbrev, lift);
     if constexpr (!LAST) {
         __syncthreads();
         fwd_schedule<A, LOGB, LOGT, S0 + K>(lds, gsrc, gdst, C, tid, pre, x, sbrev, lift);
@@ -82,7 +96,7 @@ __device__ __forceinline__ void inv_schedule(u64* lds, const u64* gsrc, u64* gds
                                              u32 pre, int x, u32 sbrev, const u64* addend) {
     constexpr int K = pass_k_inv(LOGB, LOGT, SEND);
     constexpr int S0 = SEND - K;
-    ntt_inv_pass<A, LOGB, LOGT, S0, K, SEND == LOGB, S0 == 0, SCALE>(lds, gsrc, gdst, C, tid, pre, x, sbrev, addend);
+    ntt_inv_pass<A, LOGB, LOGT, S0, K, SEND == LOGB, S0 == 0, SCALE, TFHE_ES(6) != 0>(lds, gsrc, gdst, C, tid, pre, x, sbrev, addend);
     if constexpr (S0 != 0) {
         __syncthreads();
         inv_schedule<A, LOGB, LOGT, S0, SCALE>(lds, gsrc, gdst, C, tid, pre, x, sbrev, addend);
@@ -240,9 +254,12 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_pf(const 
         typename A::tw tw2[G2::SETS * G2::NTW];
         {
             typename A::elem v[E];
-            fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u);
-            fwd_load_tw<A, LOGB, LOGT, K1, K2, false>(tw2, C, tid, 1u);  // arrive underneath the exchange
-            fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+            if constexpr (TFHE_ES(10) != 0) fwd_load_tw<A, LOGB, LOGT, K1, K2, false>(tw2, C, tid, 1u);  // arrive underneath the exchange
+            fwd_compute<A, LOGB, LOGT, 0, K1, true, false, 0>(v, raw, nullptr, C, tid, 1u, nullptr, no_hook(), TFHE_ES(10) ? lds : nullptr);
+            if constexpr (TFHE_ES(10) == 0) {
+                fwd_load_tw<A, LOGB, LOGT, K1, K2, false>(tw2, C, tid, 1u);
+                fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+            }
         }
         __syncthreads();
         {
@@ -252,8 +269,8 @@ __global__ __launch_bounds__(1 << LOGT, TFHE_NTT_WAVES) void k_ntt_fwd_pf(const 
 #pragma unroll
             for (int i = 0; i < G2::SETS * G2::NTW; i++) pin_vgpr(tw2[i].w);  // landed before the prefetch starts
             const row_prefetcher<LOGB, LOGT> pf{raw, src + ((size_t)(next < nitems ? next : item) << LOGB) + tid, next < nitems};
-            fwd_compute<A, LOGB, LOGT, K1, K2, false, false, K2, -1, row_prefetcher<LOGB, LOGT>>(v, r2, tw2, C, tid, 1u, nullptr, pf);
-            fwd_store<A, LOGB, LOGT, K1, K2, false>(v, lds, nullptr, C, tid, 0, 0u);
+            fwd_compute<A, LOGB, LOGT, K1, K2, false, false, K2, -1, row_prefetcher<LOGB, LOGT>>(v, r2, tw2, C, tid, 1u, nullptr, pf, TFHE_ES(11) ? lds : nullptr);
+            if (!TFHE_ES(11)) fwd_store<A, LOGB, LOGT, K1, K2, false>(v, lds, nullptr, C, tid, 0, 0u);
         }
         __syncthreads();
         {
@@ -535,7 +552,7 @@ __global__ __launch_bounds__(1 << LOGT, IOMODE == 2 ? 2 : TFHE_NTT_WAVES) void k
         }
         __syncthreads();
         TFHE_STAMP(2);
-        ntt_inv_pass<A, LOGB, LOGT, K3, K2, false, false, true>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
+        ntt_inv_pass<A, LOGB, LOGT, K3, K2, false, false, true, TFHE_ES(5) != 0>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
         __syncthreads();
         TFHE_STAMP(3);
         const u32 next = item + gridDim.x;
@@ -655,7 +672,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_pair(const u64* __restric
                 fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
             }
             __syncthreads();
-            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false, TFHE_ES(2) != 0>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
             __syncthreads();
             {
                 u64 r3[E];
@@ -699,7 +716,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_pair(const u64* __restric
                 inv_store<A, LOGB, LOGT, S1, K1, true, false>(v, lds, nullptr, C, tid);
             }
             __syncthreads();
-            ntt_inv_pass<A, LOGB, LOGT, KL, K2, false, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            ntt_inv_pass<A, LOGB, LOGT, KL, K2, false, false, false, TFHE_ES(7) != 0>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
             __syncthreads();
             {
                 u64 r3[E];
@@ -759,9 +776,9 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_subpair(const u64* __rest
             const u32 tid = fresh_tid();
             if (!first) __syncthreads();  // the previous transform's last pass has read LDS
             first = false;
-            ntt_fwd_pass<A, LOGB, LOGT, 0, K1, true, false>(lds, g, nullptr, C, tid, pre, 0, 0u);
+            ntt_fwd_pass<A, LOGB, LOGT, 0, K1, true, false, TFHE_ES(4) != 0>(lds, g, nullptr, C, tid, pre, 0, 0u);
             __syncthreads();
-            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false, TFHE_ES(4) != 0>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
             __syncthreads();
             {
                 u64 r3[E];
@@ -859,11 +876,11 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_fwd_quad(const u64* __restric
             __syncthreads();  // every wave has read the last chunk / the previous transform's last pass has read LDS
             {
                 typename A::elem v[E];
-                fwd_compute<A, LOGB, LOGT, 0, K1, false, false, 0>(v, w[half], nullptr, C, tid, pre);
-                fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
+                fwd_compute<A, LOGB, LOGT, 0, K1, false, false, 0>(v, w[half], nullptr, C, tid, pre, nullptr, no_hook(), TFHE_ES(1) ? lds : nullptr);
+                if (!TFHE_ES(1)) fwd_store<A, LOGB, LOGT, 0, K1, false>(v, lds, nullptr, C, tid, 0, 0u);
             }
             __syncthreads();
-            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            ntt_fwd_pass<A, LOGB, LOGT, K1, K2, false, false, TFHE_ES(0) != 0>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
             __syncthreads();
             static_assert(G3::SETS == 2, "last pass: two register sets");
             // one register set at a time: halves the transient next to the 64 held / waiting registers
@@ -945,7 +962,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_subpair(const u64* __rest
                 inv_store<A, LOGB, LOGT, S1, K1, true, false>(v, lds, nullptr, C, tid);
             }
             __syncthreads();
-            ntt_inv_pass<A, LOGB, LOGT, KL, K2, false, false, false>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
+            ntt_inv_pass<A, LOGB, LOGT, KL, K2, false, false, false, TFHE_ES(8) != 0>(lds, nullptr, nullptr, C, tid, pre, 0, 0u);
             __syncthreads();
             ntt_inv_pass<A, LOGB, LOGT, 0, KL, false, true, false>(lds, nullptr, g, C, tid, pre, 0, 0u);
         }
@@ -2000,7 +2017,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_quad2(const u64* __restri
                 inv_store<A, LOGB, LOGT, S1, K1, true, true>(v, lds, nullptr, C, tid);
             }
             __syncthreads();
-            ntt_inv_pass<A, LOGB, LOGT, KL, K2, false, false, true>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
+            ntt_inv_pass<A, LOGB, LOGT, KL, K2, false, false, true, TFHE_ES(9) != 0>(lds, nullptr, nullptr, C, tid, 1u, 0, 0u);
             __syncthreads();
             {
                 u64 r3[E];
