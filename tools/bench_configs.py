@@ -386,6 +386,8 @@ def attach_rooflines(records):
                  "valu_issue_util_at_profiled_clock": k.get("valu_issue_util"), "profiled_clock_GHz": k.get("clock_GHz"),
                  "wave_cycles": {"waiting": k.get("SQ_WAIT_ANY_share"), "issue_stalled": k.get("SQ_WAIT_INST_ANY_share"), "issuing": k.get("SQ_ACTIVE_INST_ANY_share")},
                  "kernel_us_per_call": pc["kernel_us"]}
+            if k.get("byte_calibration"):
+                e["byte_calibration"] = k["byte_calibration"]
             if alg.get(op) and "mnist" not in r.get("config", "").lower():
                 e["traffic"] = pc["hbm_bytes"] / b                                    # HBM-side bytes per unit (all kernels of the operation)
                 e["algorithmic_bytes"] = alg[op]

@@ -25,6 +25,9 @@ FETCH_CAL, WRITE_CAL, N_SIMD, N_XCD, PEAK_HZ, HBM_PEAK = 2.0, 1.0, 1024, 8, 2.4e
 VALU_PEAK = N_SIMD * PEAK_HZ / 4
 
 
+GATHER_KERNELS = ("k_md_acc", "k_md_special_perm", "k_galois", "k_ks_top_tail_rot", "k_ks_rot_tail", "k_ntt_perm", "k_ckks_gather")
+
+
 def source_id():  # same as bench.py source_id()
     R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
@@ -88,6 +91,11 @@ for cdir in sorted(glob.glob(os.path.join(root, "case*")), key=lambda p: int(os.
             e["hbm_read_bytes"] = c["FETCH_SIZE"] * 1024.0 * FETCH_CAL
         if "WRITE_SIZE" in c:
             e["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024.0 * WRITE_CAL
+        # FETCH_SIZE x2 is calibrated (MI355X_MICROARCH.md) on 16 B/lane streaming reads only; the row kernels confirm it (1.01-1.03 x
+        # their algorithmic bytes).  Kernels that gather or scatter 8 B per lane are marked: their byte figures are counter readings,
+        # not calibrated traffic.
+        if any(t in k for t in GATHER_KERNELS):
+            e["byte_calibration"] = "uncalibrated (8 B/lane gather / scatter)"
         if "hbm_read_bytes" in e and "hbm_write_bytes" in e:
             e["hbm_bytes"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
             e["hbm_GBs"] = e["hbm_bytes"] / med
@@ -158,5 +166,6 @@ else:
             print(f"{k[:52]:52s} {e['launches']:5d} {e['mean_us']:9.1f} {e['share_of_case']:6.3f} {g('valu_frac', '%9.3f'):>9s} "
                   f"{g('valu_issue_util', '%8.3f'):>8s} {g('clock_GHz', '%5.2f'):>5s} {(('%8.3f' % (e['hbm_bytes'] / 1e9)) if 'hbm_bytes' in e else ''):>8s} "
                   f"{g('hbm_frac', '%8.3f'):>8s} {g('valu_per_wave', '%9.0f'):>9s} {g('SQ_WAIT_ANY_share', '%5.2f'):>5s} "
-                  f"{g('SQ_WAIT_INST_ANY_share', '%5.2f'):>5s} {g('SQ_ACTIVE_INST_ANY_share', '%5.2f'):>5s} {e.get('bound', ''):>5s}")
+                  f"{g('SQ_WAIT_INST_ANY_share', '%5.2f'):>5s} {g('SQ_ACTIVE_INST_ANY_share', '%5.2f'):>5s} {e.get('bound', ''):>5s}"
+                  + ("  (bytes uncalibrated: gather / scatter)" if "byte_calibration" in e else ""))
         print()
