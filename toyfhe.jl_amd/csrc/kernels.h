@@ -40,13 +40,14 @@ struct limb_sel_t {  // which context modulus each buffer limb uses (crtselect, 
 //   bit 0  k_ntt_fwd_quad middle pass     182 -> 234 VGPRs, no scratch: N = 2^16 forward 2.75 -> 3.00 TB/s (mixed ring 2.00 -> 2.12)   ON
 //   bit 5  k_ntt_inv_staged middle pass   140 -> 166 VGPRs: inverse at 2^14 + 0.7 %                                                     ON
 //   bit 7  k_ntt_inv_pair middle pass     scratch 164 -> 96 bytes                                                                       ON
+//   bit 8  k_ntt_inv_subpair middle pass  218 -> 222 VGPRs: cfg#5 key switch + 0.7 %, reference-shaped MNIST + 2 %                     ON
 //   bit 11 k_ntt_fwd_pf middle pass       234 -> 238 VGPRs: no change (3.93 / 3.95 TB/s)                                                off
 //   bit 3  fwd_schedule (block kernels)   u64 forward 117 -> 188 VGPRs: 60-bit transforms 2.06 -> 1.91 TB/s                              off
 //   bits 1, 2, 6, 9, 10 (quad first pass, k_ntt_fwd_pair, inv_schedule, k_ntt_inv_quad2, k_ntt_fwd_pf first pass): 80 - 830 bytes of scratch  off
 // The fused kernels sit at the 256-VGPR cap: the same change spills 13-20 accumulator registers per digit there (headline 61.2 k ->
 // 56.4 k ciphertext-mul/s, cfg#3 40.1 k -> 30.4 k key switches/s) -- they keep the store phase behind the pass.
 #ifndef TFHE_ES_SITES
-#define TFHE_ES_SITES 0x0a1
+#define TFHE_ES_SITES 0x1a1
 #endif
 #define TFHE_ES(bit) (((TFHE_ES_SITES) >> (bit)) & 1)
 // ---- simple schedule: one workgroup per item, passes separated by barriers ----
