@@ -264,6 +264,37 @@ def test_ckks_modraise_keyswitch_and_rotate():
         tf.keyswitch(ek, tf.CipherText(params, c.cs + c.cs))        # 4 components, rlwe_she.jl:318
 
 
+def test_chained_rotations_reuse_the_packed_result_and_forget_it_when_a_component_changes():
+    """infer.jl:140-149 chains rotated = rotate(gk, rotated): the mirror hands the previous call's packed result back instead of
+    packing its components again (CipherText._packed_image).  Same bits as a chain of ciphertexts rebuilt from their components
+    (no image), and the image is dropped as soon as a component's buffer is replaced (setindex!)."""
+    N = 1 << 12
+    R = tf.NegacyclicRing(N, chain(2**40 + 1, 4, N))
+    params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    rng = np.random.default_rng(77)
+    kp = tf.keygen(rng, params)
+    gk = tf.keygen_galois(rng, kp.priv, steps=1)
+    vals = (np.arange(1, N // 2 + 1) / N).astype(complex)
+    c = tf.encrypt(rng, kp, tf.ckks_encode(vals, params.R_cipher(), 2**40), scale=2**40)
+    a = b = c
+    for step in range(4):
+        a = tf.rotate(gk, a)                                            # image handed on
+        assert a._packed_image is not None
+        b = tf.rotate(gk, tf.CipherText(params, b.cs, b.scale))         # rebuilt: packed from the components every time
+        for x, y in zip(a.cs, b.cs):
+            assert np.array_equal(x.to_numpy(), y.to_numpy()), step
+    got = tf.ckks_decode(tf.decrypt(kp, a), 2**40)
+    assert np.abs(got - np.roll(vals, 4)).max() < 1e-6
+    # a changed component: the image must not be used
+    before = [x.to_numpy() for x in a.cs]
+    a.cs[0][0] = 12345                                                   # Base.setindex!: the element gets a new coefficient buffer
+    changed = tf.rotate(gk, a)
+    fresh = tf.rotate(gk, tf.CipherText(params, a.cs, a.scale))
+    for x, y in zip(changed.cs, fresh.cs):
+        assert np.array_equal(x.to_numpy(), y.to_numpy())
+    assert not np.array_equal(a.cs[0].to_numpy(), before[0])
+
+
 def test_keyswitch_across_two_contexts_is_ordered_on_the_device():
     """A ciphertext whose ring lives in ANOTHER context (same moduli: its own stream, tables, workspaces) key-switched with a
     key of the first: the consumer context is ordered after the producer by tfhe_ctx_wait_for (no host wait), and the result is

@@ -332,6 +332,22 @@ class CipherText:
 
     def __init__(self, params, cs, scale=None):
         self.params, self.cs, self.scale = params, tuple(cs), scale
+        # (packed [count][polys][L][N] image, the component buffers it was split into): a key switch / rotation returns its packed
+        # result split into ring elements (strided copies); a chained caller (infer.jl:140-149: rotated = rotate(gk, rotated)) hands
+        # the same elements straight back, and the next call takes the image instead of packing them again.  Ring elements never
+        # change a device buffer in place (setindex! replaces it), so identity of the buffers is validity of the image.
+        self._packed_image = None
+
+    def _remember_packed(self, image, ctx):
+        self._packed_image = (image, ctx, tuple(x.primal for x in self.cs))
+        return self
+
+    def _packed_for(self, prim, ctx):
+        """the packed image of exactly these coefficient buffers on this context, or None"""
+        pi = self._packed_image
+        if pi is not None and pi[1] is ctx and len(pi[2]) == len(prim) and all(a is b for a, b in zip(pi[2], prim)):
+            return pi[0]
+        return None
 
     def __len__(self):
         return len(self.cs)
@@ -757,7 +773,7 @@ def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
     prim = [x.coeffs_primal() for x in c.cs]               # may enqueue inverse transforms on the ciphertext ring's stream ...
     if ring.ctx is not keyring.ctx:
         keyring.ctx.wait_for(ring.ctx)                     # ... so the hand-over to the key ring's stream comes after them
-    ct = _pack(prim, ring, n, ctx=keyring.ctx)
+    ct = c._packed_for(prim, keyring.ctx) or _pack(prim, ring, n, ctx=keyring.ctx)
     out = DeviceBuffer(n * 2 * sz)
     if _galois is None:
         keyring.ctx.keyswitch(keyring.L, level, special, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n)
@@ -766,7 +782,7 @@ def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
     cs = _unpack(out, ring, n, 2, batch, primal=True, ctx=keyring.ctx)
     if ring.ctx is not keyring.ctx:
         ring.ctx.wait_for(keyring.ctx)                     # the results are elements of `ring`: its stream must see them written
-    return CipherText(c.params, cs, c.scale)
+    return CipherText(c.params, cs, c.scale)._remember_packed(out, keyring.ctx)
 
 
 def apply_galois_element(c: CipherText, g: int) -> CipherText:
