@@ -2057,11 +2057,13 @@ __global__ __launch_bounds__(1 << LOGT) void k_ntt_inv_quad2(const u64* __restri
 // fold_ninv: the words are multiplied by N^-1 mod q_j on the way (k_ks_fused runs its inverse transforms unscaled).
 __global__ __launch_bounds__(256) void k_evk_to_f64(const u64* __restrict__ evk, u64* __restrict__ evd,
                                                      const ntt_limb_t* __restrict__ LT, ks_arg_t KA, int Lk, u32 n, int fold_ninv, int x,
-                                                     u64 ginv) {
+                                                     u64 ginv, int pair) {
     const u32 row = blockIdx.x, j = row % (u32)KA.nw, ic = row / (u32)KA.nw;
     const ntt_limb_t& L = LT[KA.w.idx[j]];
     const u64* s = evk + ((size_t)ic * Lk + KA.w.idx[j]) * n;
-    u64* d = evd + (size_t)row * n;
+    // pair (k_ks_fused, r05): the two components of digit i interleaved word by word -- evd[(i nw + j)][k][comp] -- so that the
+    // product phase takes both key words of a position with ONE 16-byte load (half the load instructions in flight for the same bytes)
+    u64* d = pair ? evd + (((size_t)(ic >> 1) * KA.nw + j) * n) * 2 + (ic & 1u) : evd + (size_t)row * n;
     for (u32 k = blockIdx.y * blockDim.x + threadIdx.x; k < n; k += gridDim.y * blockDim.x) {
         // ginv != 0: the key of x -> x^g PREPARED on the way (rows permuted by g^-1, as tfhe_galois_key_prepare) -- the rotation in the
         // tail (k_ks_top_tail_rot): the key sums of the UNrotated digits are then sigma_g^-1 of the rotated ciphertext's
@@ -2074,7 +2076,8 @@ __global__ __launch_bounds__(256) void k_evk_to_f64(const u64* __restrict__ evk,
         __builtin_memcpy(&b, &v, 8);
         // x > 0 (k_ks_fused_sub at N = 2^16, x = 2): a sub-block reads the words at positions (nat << x) + c -- stored class by
         // class (c major), so that its lanes read consecutive words instead of every 2^x-th one
-        d[x ? ((size_t)(k & ((1u << x) - 1u)) * (n >> x)) + (k >> x) : k] = b;
+        const size_t pos = x ? ((size_t)(k & ((1u << x) - 1u)) * (n >> x)) + (k >> x) : (size_t)k;
+        d[pair ? pos * 2 : pos] = b;
     }
 }
 // PRELIFT: the rows of c[end] arrive as centred doubles (bfv_contract_narrow<.., LIFTED>): the lift is a bit cast
@@ -2134,8 +2137,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
             kst(1);
             fused_fwd_to_regs<A, LOGB, LOGT, PRELIFT, (TFHE_TWL_KS & 1) != 0>(lds, grow, C, first, v, &lf);
             // multiply-accumulate with the key: component 1 (masked) feeds out_0, component 0 (mask) feeds out_1
-            const u64* e_mask = evd + ((((size_t)i * 2 + 0) * nw + j) << LOGB);    // key words as doubles (k_evk_to_f64)
-            const u64* e_masked = evd + ((((size_t)i * 2 + 1) * nw + j) << LOGB);
+            const u64x2_t* e_pair = (const u64x2_t*)(evd + ((((size_t)i * nw + j) << LOGB) << 1));   // key words as doubles, (mask, masked) per position (k_evk_to_f64, pair)
 #pragma unroll
             for (int u = 0; u < G3::SETS; u++) {
                 u32 c0, hi, base;
@@ -2147,7 +2149,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused(const u64* __restrict__ 
 #ifdef TFHE_ABL_NOKEYS  // design aid: key words from arithmetic (wrong results, no key traffic)
                     const typename A::tw k1{(double)(nat | 1u) * 4097.0 + C.pinv}, k0{(double)(nat | 3u) * 257.0 + C.pinv};
 #else
-                    const typename A::tw k1{A::from_lds(e_masked[nat])}, k0{A::from_lds(e_mask[nat])};
+                    const u64x2_t kw = e_pair[nat];
+                    const typename A::tw k1{A::from_lds(kw.y)}, k0{A::from_lds(kw.x)};
 #endif
                     // range: y reduced to |y| <= p/2, so every term is <= (1/2 + 0.75 a) p = 0.69 p and eight of them stay
                     // below the 7.9 p exactness limit (fp64arith.h); the accumulators are swept every eighth digit
@@ -2328,8 +2331,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
             // switches/s on 7 x 50 bit; at X = 1 the same layout cost 24 more spilled registers and 2.8 % at cfg#3: interleaved there)
             constexpr bool CM = X == 2;
             const size_t eoff = CM ? ((size_t)brev_bits(sb, X) << LOGB) : (size_t)brev_bits(sb, X);
-            const u64* e_mask = evd + ((((size_t)i * 2 + 0) * nw + j) << (LOGB + X)) + eoff;
-            const u64* e_masked = evd + ((((size_t)i * 2 + 1) * nw + j) << (LOGB + X)) + eoff;
+            const u64x2_t* e_pair = (const u64x2_t*)(evd + ((((size_t)i * nw + j) << (LOGB + X)) << 1)) + eoff;   // (mask, masked) per position (k_evk_to_f64, pair)
 #pragma unroll
             for (int u = 0; u < G3::SETS; u++) {
                 u32 c0, hi, base;
@@ -2338,7 +2340,8 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                 for (int r = 0; r < G3::R; r++) {
                     const u32 nat = (brev_bits((u32)r, K3) << (LOGB - K3)) + c0;
                     const int e = u * G3::R + r;
-                    const typename A::tw k1{A::from_lds(e_masked[CM ? nat : nat << X])}, k0{A::from_lds(e_mask[CM ? nat : nat << X])};
+                    const u64x2_t kw = e_pair[CM ? nat : nat << X];
+                    const typename A::tw k1{A::from_lds(kw.y)}, k0{A::from_lds(kw.x)};
                     const double y = A::pre_product(v[e], C);  // range: as k_ks_fused
                     acc[0][e] += fp_mulmod_c(y, k1, C.p, C.pinv);
                     acc[1][e] += fp_mulmod_c(y, k0, C.p, C.pinv);

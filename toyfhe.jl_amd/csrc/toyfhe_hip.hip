@@ -1564,7 +1564,7 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
         for (int j = 0; j < level; j++) KA.w.idx[j] = j;
         if (special) KA.w.idx[level] = Lk - 1;
         hipLaunchKernelGGL(k_evk_to_f64, row_grid((unsigned)(level * 2 * nw), N), dim3(256), 0, c->stream, evk, evd, c->limbs_dev, KA, Lk, (u32)N, c->logN <= 14 ? 1 : 0, c->logN == 16 ? 2 : 0,
-                           rot_in_tail ? inv_mod_2n(galois, 2 * (u64)c->N) : (u64)0);
+                           rot_in_tail ? inv_mod_2n(galois, 2 * (u64)c->N) : (u64)0, 1);
         HIP_TRY(hipGetLastError());
     }
     if (rot_key_prep) {
