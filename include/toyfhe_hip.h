@@ -165,6 +165,11 @@ int tfhe_galois(tfhe_ctx *ctx, const uint64_t *src, uint64_t *dst, uint64_t galo
 int tfhe_keyswitch(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint64_t *evk, int n_digits, const uint64_t *ct, int polys, uint64_t *out, int64_t batch);
 /* rotate(gk, c) = keyswitch(gk, apply_galois_element(c, g)) (rlwe_she.jl:355-359) */
 int tfhe_rotate(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint64_t *evk, int n_digits, uint64_t galois_element, const uint64_t *ct, uint64_t *out, int64_t batch);
+/* the same with the key already prepared by tfhe_galois_key_prepare for this galois_element (below): a caller that rotates by one
+ * Galois element again and again (infer.jl:140-149: 63 chained rotate(gk, rotated) per matrix product, ONE key) prepares the key
+ * once instead of once per call.  Bit-identical to tfhe_rotate on the plain key. */
+int tfhe_rotate_prepared(tfhe_ctx *ctx, int key_limbs, int level, int special, const uint64_t *evk_prepared, int n_digits, uint64_t galois_element,
+                         const uint64_t *ct, uint64_t *out, int64_t batch);
 
 /* Hoisted rotations: out[r] = rotate(gk_r, c) for r < n_rot from one digit decomposition of c (the RNS digits commute with
  * the automorphism; in the NTT domain it is an index permutation), bit-identical to n_rot calls of tfhe_rotate at

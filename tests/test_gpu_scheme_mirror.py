@@ -278,8 +278,10 @@ def test_chained_rotations_reuse_the_packed_result_and_forget_it_when_a_componen
     c = tf.encrypt(rng, kp, tf.ckks_encode(vals, params.R_cipher(), 2**40), scale=2**40)
     a = b = c
     for step in range(4):
+        prev = a
         a = tf.rotate(gk, a)                                            # image handed on
         assert a._packed_image is not None
+        assert prev._packed_image is None                               # ... and forgotten by the ciphertext it was taken from (r06)
         b = tf.rotate(gk, tf.CipherText(params, b.cs, b.scale))         # rebuilt: packed from the components every time
         for x, y in zip(a.cs, b.cs):
             assert np.array_equal(x.to_numpy(), y.to_numpy()), step

@@ -94,7 +94,9 @@ def test_shim_binds_the_whole_hot_path():
             "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg", "tfhe_mul", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale",
             "tfhe_select_limbs", "tfhe_galois", "tfhe_keyswitch", "tfhe_rotate", "tfhe_keyswitch_window", "tfhe_ckks_encode",
             "tfhe_ckks_decode", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_mul", "tfhe_bfv_mul_relin",
-            "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_last_error", "tfhe_ctx_sync", "tfhe_set_device"}
+            "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_last_error", "tfhe_ctx_sync", "tfhe_set_device",
+            # r06: the weighted sums bound directly, rotations on prepared keys
+            "tfhe_lincomb", "tfhe_lincomb_many", "tfhe_rotate_prepared", "tfhe_rotate_many", "tfhe_matmul_diag", "tfhe_galois_key_prepare"}
     assert need <= bound, sorted(need - bound)
 
 

@@ -123,24 +123,50 @@ inline void set_stream(hipStream_t* sp, hipStream_t v) {
     *sp = v;
 }
 
-// move parked blocks whose events have all completed to the ready lists (front of the queue first; stop at the first busy one)
-inline void poll_locked(dev_state_t& d) {
+// move parked blocks whose events have all completed to the ready lists (front of the queue first; stop at the first busy one).
+// Only hipErrorNotReady means "busy": any other status is a device error (fault, reset, a destroyed stream) and comes back to the
+// caller -- a waiting alloc() must not spin on it (r06).
+inline hipError_t poll_locked(dev_state_t& d) {
     while (!d.parked.empty()) {
         parked_t& b = d.parked.front();
-        bool done = true;
-        for (hipEvent_t ev : b.evs)
-            if (hipEventQuery(ev) != hipSuccess) { done = false; break; }
-        if (!done) { (void)hipGetLastError(); break; }
+        for (hipEvent_t ev : b.evs) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q == hipSuccess) continue;
+            (void)hipGetLastError();
+            return q == hipErrorNotReady ? hipSuccess : q;
+        }
         for (hipEvent_t ev : b.evs) d.ev_pool.push_back(ev);
         if (b.p) d.ready[b.bytes].push_back(b.p);                // (p == nullptr: the events of a block alloc_ws took while parked)
         d.parked.pop_front();
     }
+    return hipSuccess;
+}
+// the oldest parked block of exactly `bytes`, queried directly (a busy, unrelated block at the front of the queue does not hide it):
+// *found = one is parked; returns hipSuccess with *out set when its events have completed (the block leaves the queue, its
+// events go back to the pool), hipErrorNotReady while they have not, any other status on a device error
+inline hipError_t take_parked_locked(dev_state_t& d, size_t bytes, void** out, bool* found) {
+    *found = false;
+    for (auto it = d.parked.begin(); it != d.parked.end(); ++it) {
+        if (!it->p || it->bytes != bytes) continue;
+        *found = true;
+        for (hipEvent_t ev : it->evs) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q == hipSuccess) continue;
+            (void)hipGetLastError();
+            return q;
+        }
+        for (hipEvent_t ev : it->evs) d.ev_pool.push_back(ev);
+        *out = it->p;
+        d.parked.erase(it);
+        return hipSuccess;
+    }
+    return hipErrorNotReady;
 }
 // give everything cached on the CURRENT device back to the driver (after draining it)
 inline void trim_locked(state_t& s) {
     dev_state_t& d = dev_locked(s, current_device());
     (void)hipDeviceSynchronize();
-    poll_locked(d);
+    (void)poll_locked(d);
     for (auto& kv : d.ready)
         for (void* p : kv.second) (void)hipFree(p);
     d.ready.clear();
@@ -195,7 +221,7 @@ inline hipError_t alloc(size_t bytes, void** out) {
         d.want_trim = false;
         if (d.cached_bytes > d.max_cached) trim_locked(s);
     }
-    poll_locked(d);
+    (void)poll_locked(d);
     d.last_use[bytes] = ++d.seq;
     auto it = d.ready.find(bytes);
     if ((it == d.ready.end() || it->second.empty()) && d.cached_bytes > d.soft_cached) {
@@ -212,18 +238,23 @@ inline hipError_t alloc(size_t bytes, void** out) {
             // unlocked, so synchronising on copied handles could block on unrelated later work.  Between polls the mutex is free
             // (release() on finalizer threads never waits behind this); the loop ends when a block of this size is ready or none
             // of this size is parked any more (a trim on another thread).
-            for (unsigned spin = 0;; spin++) {
+            // r06: the block waited for is the oldest parked one of THIS size, queried directly; a device error or a wait
+            // beyond MAX_WAIT_SPINS (about two seconds: a wedged stream) ends the loop and the request falls through to hipMalloc,
+            // which reports what the device has to say.
+            constexpr unsigned MAX_WAIT_SPINS = 100000;
+            for (unsigned spin = 0; spin < MAX_WAIT_SPINS; spin++) {
                 it = d.ready.find(bytes);
                 if (it != d.ready.end() && !it->second.empty()) break;
+                void* got = nullptr;
                 bool parked_one = false;
-                for (const parked_t& b : d.parked)
-                    if (b.p && b.bytes == bytes) { parked_one = true; break; }
-                if (!parked_one) break;
+                const hipError_t q = take_parked_locked(d, bytes, &got, &parked_one);
+                if (q == hipSuccess && got) { d.ready[bytes].push_back(got); break; }
+                if (!parked_one || q != hipErrorNotReady) break;
                 g.unlock();
                 if (spin < 256) std::this_thread::yield();
                 else std::this_thread::sleep_for(std::chrono::microseconds(20));
                 g.lock();
-                poll_locked(d);
+                if (poll_locked(d) != hipSuccess) break;
             }
         }
         it = d.ready.find(bytes);
@@ -261,7 +292,7 @@ inline hipError_t alloc_ws(size_t bytes, hipStream_t stream, void** out, size_t*
         if (s.enabled) {
             const int dev = current_device();
             dev_state_t& d = dev_locked(s, dev);
-            poll_locked(d);
+            (void)poll_locked(d);
             size_t best = 0;
             for (auto& kv : d.ready)
                 if (kv.first >= bytes && kv.first <= 2 * bytes && !kv.second.empty() && (best == 0 || kv.first < best)) best = kv.first;

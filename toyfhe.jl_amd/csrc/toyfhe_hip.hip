@@ -57,8 +57,15 @@ struct tfhe_ctx {
     ntt_limb_t* limbs_dev = nullptr;
     std::vector<void*> tabs;   // device twiddle tables (W, Winv and their fp64 twins per limb)
     int num_cus = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // the stream launches go to: main_stream, or side_stream inside a forked region (lanes_t)
+    hipStream_t main_stream = nullptr;   // the context's stream as its users know it (the slot the allocator records release events on)
     bool own_stream = false;
+    // second lane (r06): rings that mix the two arithmetic policies (60-bit q0 / special prime beside 40-bit primes) run the
+    // launches of one policy on side_stream beside those of the other, forked from and joined back into main_stream by events
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int lane_depth = 0;                  // > 0: inside a forked region (nested lanes_t objects only switch streams)
+    bool lanes_broken = false;           // creating the second stream failed once: stay serial
     int variant = 0;
     // workspace (grown on demand, reused)
     void* ws = nullptr;
@@ -138,6 +145,62 @@ size_t ws_keep_bytes() {
     return keep;
 }
 
+// ---- two lanes ------------------------------------------------------------------------------------------------------------
+// A ring that mixes fp64-size moduli with larger ones runs every transform / key-switch step as two sets of launches, one per
+// arithmetic policy, over DISJOINT limb rows.  Serialised on one stream each set drains before the other starts, and on small
+// batches (one ciphertext = a few dozen workgroup items) each leaves most of the 256 CUs idle.  lanes_t forks the context's
+// stream: lane 0 stays on main_stream, lane 1 goes to side_stream, which starts after everything main_stream held at the fork;
+// the outermost lanes_t joins the side lane back in its destructor (main waits for an event recorded on side), so the caller
+// -- and the allocator, which records release events on main_stream only -- see ONE stream as before.  Nested lanes_t objects
+// (a step inside a forked region) only switch lanes: data that stays within one policy's limbs flows in stream order on its
+// own lane across steps without a join.  Whatever both lanes need (workspace growth: ensure_ws may synchronise or free) must be
+// done BEFORE the fork.  TFHE_LANES=0 keeps everything on one stream (comparisons).
+struct lanes_t {
+    tfhe_ctx* c;
+    bool owner = false, on = false;
+    hipStream_t entry = nullptr;
+    explicit lanes_t(tfhe_ctx* ctx, bool want = true) : c(ctx) {
+        static const bool enabled = !(getenv("TFHE_LANES") && getenv("TFHE_LANES")[0] == '0');
+        entry = c->stream;
+        if (!want || !enabled || c->lanes_broken) return;
+        if (c->lane_depth > 0) { on = true; c->lane_depth++; return; }
+        if (!c->side_stream) {
+            bool ok = hipStreamCreate(&c->side_stream) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); c->lanes_broken = true; return; }
+        }
+        if (hipEventRecord(c->ev_fork, c->main_stream) != hipSuccess || hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            c->lanes_broken = true;
+            return;
+        }
+        owner = on = true;
+        c->lane_depth = 1;
+    }
+    // launches that follow go to lane `l` (0 = main, 1 = side); without a fork both are the entry stream
+    void use(int l) { if (on) c->stream = l ? c->side_stream : c->main_stream; }
+    int join() {   // idempotent; the destructor calls it
+        if (!on) return TFHE_OK;
+        on = false;
+        c->lane_depth--;
+        c->stream = entry;
+        if (!owner) return TFHE_OK;
+        c->stream = c->main_stream;
+        hipError_t e = hipEventRecord(c->ev_join, c->side_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->main_stream, c->ev_join, 0);
+        if (e != hipSuccess) {   // never leave the side lane unordered: wait for it on the host
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(c->side_stream);
+            c->lanes_broken = true;
+        }
+        return TFHE_OK;
+    }
+    ~lanes_t() { (void)join(); }
+    lanes_t(const lanes_t&) = delete;
+    lanes_t& operator=(const lanes_t&) = delete;
+};
+
 int make_sel(const tfhe_ctx* c, int limbs, const int32_t* idx, limb_sel_t* sel) {
     if (limbs < 1 || limbs > TFHE_MAX_LIMBS) return fail(TFHE_E_BADARG, "limbs=%d out of range [1,%d]", limbs, TFHE_MAX_LIMBS);
     sel->n = limbs;
@@ -181,7 +244,11 @@ bool sel_fp(const tfhe_ctx* c, const limb_sel_t& sel, int x) {
 ntt_io_t io_plain() { ntt_io_t io; memset(&io, 0, sizeof io); return io; }
 // a ring of mixed modulus sizes is split into one pass per arithmetic policy only when there is enough work to pay for the
 // second set of launches (a single ciphertext at N = 2^16 is 0.9 M words and stays on the u64 kernels)
-#define TFHE_MIXED_MIN_WORDS (1ll << 20)
+static long long mixed_min_words() {   // TFHE_MIXED_MIN_LOG2 overrides (measurements)
+    static const long long v = [] { const char* e = getenv("TFHE_MIXED_MIN_LOG2"); const int l = e ? atoi(e) : -1; return 1ll << ((l >= 0 && l < 40) ? l : 20); }();
+    return v;
+}
+#define TFHE_MIXED_MIN_WORDS mixed_min_words()
 
 template <class A, int LOGB, int IOMODE = 0>
 int launch_block_fwd(tfhe_ctx* c, const u64* src, u64* dst, int64_t rows, const limb_sel_t& sel, int x, const ntt_io_t& io) {
@@ -487,26 +554,32 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
             ntt_io_t a = io, b = io;
             a.limb_mask = fpmask;
             b.limb_mask = all & ~fpmask;
+            // the two policies side by side (lanes_t): the u64 launches -- the long pole -- first, on the main lane
+            lanes_t lanes(c);
             if (io.mode == 1) {
                 int rc1 = TFHE_E_UNSUPPORTED;
+                lanes.use(0);
                 switch (n) {
-                    case 12: rc1 = launch_block_fwd<ArithFpWide, 12, 1>(c, src, dst, rows, sel, 0, a); break;
-                    case 13: rc1 = launch_block_fwd<ArithFpWide, 13, 1>(c, src, dst, rows, sel, 0, a); break;
-                    case 14: rc1 = launch_block_fwd<ArithFpWide, 14, 1>(c, src, dst, rows, sel, 0, a); break;
+                    case 12: rc1 = launch_block_fwd<ArithInt, 12, 1>(c, src, dst, rows, sel, 0, b); break;
+                    case 13: rc1 = launch_block_fwd<ArithInt, 13, 1>(c, src, dst, rows, sel, 0, b); break;
+                    case 14: rc1 = launch_block_fwd<ArithInt, 14, 1>(c, src, dst, rows, sel, 0, b); break;
                 }
                 if (rc1) return rc1;
+                lanes.use(1);
                 switch (n) {
-                    case 12: return launch_block_fwd<ArithInt, 12, 1>(c, src, dst, rows, sel, 0, b);
-                    case 13: return launch_block_fwd<ArithInt, 13, 1>(c, src, dst, rows, sel, 0, b);
-                    default: return launch_block_fwd<ArithInt, 14, 1>(c, src, dst, rows, sel, 0, b);
+                    case 12: return launch_block_fwd<ArithFpWide, 12, 1>(c, src, dst, rows, sel, 0, a);
+                    case 13: return launch_block_fwd<ArithFpWide, 13, 1>(c, src, dst, rows, sel, 0, a);
+                    default: return launch_block_fwd<ArithFpWide, 14, 1>(c, src, dst, rows, sel, 0, a);
                 }
             }
             switch (n) {
 #define CASE_(LB)                                                                                                  \
     case LB: {                                                                                                     \
-        int rc1 = inverse ? launch_block_inv<ArithFp, LB>(c, src, dst, rows, sel, 0, a) : launch_block_fwd<ArithFp, LB>(c, src, dst, rows, sel, 0, a); \
+        lanes.use(0);                                                                                              \
+        int rc1 = inverse ? launch_block_inv<ArithInt, LB>(c, src, dst, rows, sel, 0, b) : launch_block_fwd<ArithInt, LB>(c, src, dst, rows, sel, 0, b); \
         if (rc1) return rc1;                                                                                       \
-        return inverse ? launch_block_inv<ArithInt, LB>(c, src, dst, rows, sel, 0, b) : launch_block_fwd<ArithInt, LB>(c, src, dst, rows, sel, 0, b); \
+        lanes.use(1);                                                                                              \
+        return inverse ? launch_block_inv<ArithFp, LB>(c, src, dst, rows, sel, 0, a) : launch_block_fwd<ArithFp, LB>(c, src, dst, rows, sel, 0, a); \
     }
                 CASE_(10) CASE_(11) CASE_(12) CASE_(13) CASE_(14)
 #undef CASE_
@@ -529,9 +602,16 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
             ntt_io_t a = io, b = io;
             a.limb_mask = fpmask;
             b.limb_mask = all & ~fpmask;
-            int rc1 = run_ntt_large(c, inverse, src, dst, rows, sel, a, nullptr, true);
+            // the transform scratch of both policies (disjoint rows of it) is sized before the fork: growing it synchronises
+            void* tmp = nullptr;
+            int rc1 = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
             if (rc1) return rc1;
-            return run_ntt_large(c, inverse, src, dst, rows, sel, b, nullptr, false);
+            lanes_t lanes(c);
+            lanes.use(0);   // the u64 launches (top stages + block kernel: the long pole) first, on the main lane
+            rc1 = run_ntt_large(c, inverse, src, dst, rows, sel, b, nullptr, false);
+            if (rc1) return rc1;
+            lanes.use(1);
+            return run_ntt_large(c, inverse, src, dst, rows, sel, a, nullptr, true);
         }
     }
     return run_ntt_large(c, inverse, src, dst, rows, sel, io, iop, sel_fp(c, sel, n - 14));
@@ -688,14 +768,19 @@ int tfhe_ctx_create(int64_t N, int L, const uint64_t* q, const uint64_t* psi, tf
             c->num_cus = cus;
     }
     c->own_stream = true;
-    devalloc::register_stream(&c->stream);
+    c->main_stream = c->stream;
+    devalloc::register_stream(&c->main_stream);
     *out = c;
     return TFHE_OK;
 }
 
 int tfhe_ctx_destroy(tfhe_ctx* c) {
     if (!c) return TFHE_OK;
-    devalloc::unregister_stream(&c->stream);
+    devalloc::unregister_stream(&c->main_stream);
+    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    c->stream = c->main_stream;
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto* t : c->tabs) hipFree(t);
     for (auto* t : c->ksw_allocs) hipFree(t);
@@ -718,7 +803,8 @@ int tfhe_ctx_set_stream(tfhe_ctx* c, void* s) {
     if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
     hipStream_t old = c->own_stream ? c->stream : nullptr, fresh = (hipStream_t)s;
     if (!s) HIP_TRY(hipStreamCreate(&fresh));
-    devalloc::set_stream(&c->stream, fresh);                       // the allocator reads the slot under its mutex (tfhe_free)
+    devalloc::set_stream(&c->main_stream, fresh);                  // the allocator reads the slot under its mutex (tfhe_free)
+    c->stream = fresh;
     c->own_stream = (s == nullptr);
     if (old) hipStreamDestroy(old);
     return TFHE_OK;
@@ -1106,14 +1192,17 @@ static int ks_digits_fwd(tfhe_ctx* c, const ks_arg_t& A, const u64* ct, u64* dig
     } else if (lift_mixed) {
         ntt_io_t io = io_plain();
         io.mode = 1; io.level = (u32)level; io.nw = (u32)nw; io.polys = (u32)polys; io.limb_mask = fpmask;
-        rc = run_ntt_large(c, false, ct, dig, batch * level * nw, A.w, io, &io, true, true);
-        if (rc) return rc;
-        // the larger working limbs: lift fused into the top-stage kernel (into the transform scratch), then the u64 block kernels
         const int64_t rows = batch * level * nw;
         const int x = c->logN - 14;
         void* tmp = nullptr;
-        rc = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
+        rc = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);   // (before the fork: growing the workspace synchronises)
         if (rc) return rc;
+        lanes_t lanes(c);   // the fp64-size working limbs on the side lane, beside the u64 ones
+        lanes.use(1);
+        rc = run_ntt_large(c, false, ct, dig, rows, A.w, io, &io, true, true);
+        if (rc) return rc;
+        lanes.use(0);
+        // the larger working limbs: lift fused into the top-stage kernel (into the transform scratch), then the u64 block kernels
         ntt_io_t iw = io;
         iw.limb_mask = allmask & ~fpmask;
         const dim3 tg((unsigned)((((c->N >> x) + 255) / 256) * rows));
@@ -1166,16 +1255,21 @@ static int md_lift_fwd(tfhe_ctx* c, const ks_arg_t& A, const limb_sel_t& sl, con
         const bool special_fp = c->limbs_host[A.w.idx[level]].Wd != nullptr;
         if ((rows << x) > 0x7fffffffll || (((uintptr_t)P | (uintptr_t)U) & 15u) != 0) return fail(TFHE_E_BADARG, "md_lift_fwd: row count / alignment");
         int rc;
+        void* tmp = nullptr;
+        if (tmask != tall) {   // (before the fork: growing the workspace synchronises)
+            rc = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
+            if (rc) return rc;
+        }
+        lanes_t lanes(c, tmask != 0 && tmask != tall);   // both kinds of limbs: side by side
         if (tmask) {   // the fp64-size limbs: one kernel per row (pair) (ArithFpWide reads a source above 2^52 in two halves)
             ntt_io_t a = io;
             a.limb_mask = tmask == tall ? 0u : tmask;
+            lanes.use(1);
             rc = run_ntt_large(c, false, P, U, rows, sl, a, &a, true, !special_fp);
             if (rc) return rc;
+            lanes.use(0);
         }
         if (tmask != tall) {   // the larger limbs: lift fused into the top stages (into the transform scratch), then the u64 block kernels
-            void* tmp = nullptr;
-            rc = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
-            if (rc) return rc;
             ntt_io_t w = io;
             w.limb_mask = tmask ? (tall & ~tmask) : 0u;
             const dim3 tg((unsigned)((((c->N >> x) + 255) / 256) * rows));
@@ -1223,7 +1317,9 @@ static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* ev
     u32 nmask = mask_of(nw, [&](int j) { return (c->limbs_host[A.w.idx[j]].q >> 52) == 0; });
     const u32 amask = mask_all(nw);
     if (n % 2 != 0) nmask = 0;
+    lanes_t lanes(c, nmask != 0 && nmask != amask);   // both kernels: side by side (disjoint working limbs)
     if (nmask) {
+        lanes.use(1);
         const unsigned gx2 = (n / 2 + 255) / 256;
         const unsigned bs2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(batch, (4096 + nw * gx2 * gy - 1) / (nw * gx2 * gy)));
         auto kn = epi_x ? k_ks_inner_n2<8, true> : k_ks_inner_n2<8, false>;
@@ -1231,6 +1327,7 @@ static int ks_inner_launch(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* ev
                            nmask == amask ? 0u : nmask, K);
     }
     if (nmask != amask) {
+        lanes.use(0);
         auto kg = epi_x ? k_ks_inner<8, true> : k_ks_inner<8, false>;
         hipLaunchKernelGGL(kg, multi((unsigned)nw * gx * bsplit), dim3(256), 0, c->stream, evk, dig, S, c->limbs_dev, A, Lk, n, (u32)batch, bsplit,
                            nmask ? (amask & ~nmask) : 0u, K);
@@ -1252,8 +1349,10 @@ static bool ks_tail16(const tfhe_ctx* c, const ks_arg_t& A) {
 }
 // g_tail != 0: a rotation finished in the tail (k_ks_top_tail_rot<2>; N = 2^16 path only): `evk` is the prepared key, `ct` the
 // UNrotated input
+// `outer`: the caller's forked region (ks_chunk) -- the steps up to the inverse sub-block transforms stay on their lanes, the
+// join comes before the tail, which reads every limb
 static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, const u64* ct, u64* out, int64_t batch, u64* S,
-                     const u64* dig, u64* tbuf, u64 g, u64 g_tail = 0) {
+                     const u64* dig, u64* tbuf, u64 g, u64 g_tail = 0, lanes_t* outer = nullptr) {
     const int level = A.level, nw = A.nw, polys = A.polys, special = A.special;
     const u32 n = (u32)c->N;
     const u32 add_s = polys == 3 ? 2u : 1u;  // c2 starts from zero for a 2-element input (rlwe_she.jl:324)
@@ -1264,6 +1363,7 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
     const u32 amask = mask_all(nw);
     (void)gx;
     if (g != 0) {  // hoisted rotation: INTT, automorphism, tail
+        if (outer) outer->join();
         rc = run_ntt(c, true, S, S, batch * 2 * nw, A.w);
         if (rc) return rc;
         rc = do_galois(c, S, tbuf, g, batch * 2 * nw, A.w);
@@ -1288,14 +1388,20 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
         // N = 2^16: the paired sub-block inverse into the (now free) digit buffer, then the two inverse top stages together with
         // the tail (k_ks_top_tail<2>) instead of k_ntt_inv_top<2> + k_ks_rescale_add / k_ks_add_ct.  Rings of mixed modulus sizes:
         // the larger limbs' sub-blocks come from the u64 block kernel (same sub-block layout, lazy [0, 2q) outputs).
-        rc = launch_subpair<ArithFp>(c, true, S, tbuf, batch * 2 * nw, A.w, 2, fpm == amask ? 0u : fpm);
-        if (rc) return rc;
-        if (fpm != amask) {
-            ntt_io_t iw = io_plain();
-            iw.limb_mask = amask & ~fpm;
-            rc = launch_block_inv<ArithInt, 14>(c, S, tbuf, batch * 2 * nw, A.w, 2, iw);
+        {
+            lanes_t lanes(c, fpm != amask);
+            lanes.use(1);
+            rc = launch_subpair<ArithFp>(c, true, S, tbuf, batch * 2 * nw, A.w, 2, fpm == amask ? 0u : fpm);
             if (rc) return rc;
+            if (fpm != amask) {
+                lanes.use(0);
+                ntt_io_t iw = io_plain();
+                iw.limb_mask = amask & ~fpm;
+                rc = launch_block_inv<ArithInt, 14>(c, S, tbuf, batch * 2 * nw, A.w, 2, iw);
+                if (rc) return rc;
+            }
         }
+        if (outer) outer->join();
         rescale_arg_t ra;
         memset(&ra, 0, sizeof ra);
         if (special) {
@@ -1307,6 +1413,7 @@ static int ks_finish(tfhe_ctx* c, const ks_arg_t& A, int Lk, const u64* evk, con
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
+    if (outer) outer->join();
     if (special) {
         rc = run_ntt(c, true, S, S, batch * 2 * nw, A.w);
         if (rc) return rc;
@@ -1488,9 +1595,22 @@ static int ks_chunk(tfhe_ctx* c, int Lk, int level, int special, const u64* evk,
         HIP_TRY(hipGetLastError());
         return TFHE_OK;
     }
+    // Rings of mixed modulus sizes at N = 2^16 (the three-kernel path): when the digit transforms, the key sums and the inverse
+    // sub-block transforms all split the working limbs the same way (fp64-size = "narrow"), the two policies run as two lanes
+    // from the lift to the inverse with ONE join before the tail; otherwise every step forks and joins by itself.
+    const u32 fpm = mask_of(nw, [&](int j) { return c->limbs_host[A.w.idx[j]].Wd != nullptr; });
+    const u32 nrw = mask_of(nw, [&](int j) { return (c->limbs_host[A.w.idx[j]].q >> 52) == 0; });
+    const bool two_lanes = nw <= 32 && c->variant == 0 && c->logN == 16 && fpm != 0 && fpm != mask_all(nw) && fpm == nrw && ks_tail16(c, A) &&
+                           (((uintptr_t)ct | (uintptr_t)dig | (uintptr_t)S) & 15u) == 0;
+    if (two_lanes) {
+        void* tmp = nullptr;
+        rc = ensure_ws(c, (size_t)batch * level * nw * c->N * 8, &tmp);   // (no-op under keyswitch_impl; before the fork)
+        if (rc) return rc;
+    }
+    lanes_t outer(c, two_lanes);
     rc = ks_digits_fwd(c, A, ct, dig, batch);
     if (rc) return rc;
-    return ks_finish(c, A, Lk, evk, ct, out, batch, S, dig, dig, 0, g_tail);
+    return ks_finish(c, A, Lk, evk, ct, out, batch, S, dig, dig, 0, g_tail, &outer);
 }
 
 static int ks_check(tfhe_ctx* c, int Lk, int level, int special, const void* evk, int n_digits, const void* ct, int polys, const void* out, int64_t batch) {
@@ -1505,8 +1625,11 @@ static int ks_check(tfhe_ctx* c, int Lk, int level, int special, const void* evk
 }
 
 static u64 inv_mod_2n(u64 g, u64 twoN);
+// key_prepared (rotations only, tfhe_rotate_prepared): `evk` is the output of tfhe_galois_key_prepare for `galois` -- the paths that
+// finish the rotation in their tail consume it as it is (no per-call k_ntt_perm / permuting conversion); the others take the
+// hoisted form of tfhe_rotate_many, which is defined on prepared keys (same bits)
 static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64* evk, const u64* ct, int polys, u64* out, int64_t batch,
-                          u64 galois, bool rotate, bool prelifted = false) {
+                          u64 galois, bool rotate, bool prelifted = false, bool key_prepared = false) {
     if (prelifted && (rotate || special || !ks_prelift_ok(c, level))) return fail(TFHE_E_UNSUPPORTED, "internal: pre-lifted rows need the fused key switch");
     const int nw = special ? level + 1 : level;
     const size_t N = (size_t)c->N;
@@ -1536,6 +1659,11 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
         if (special) KA.w.idx[level] = Lk - 1;
         if (ks_tail16(c, KA)) rot_in_tail = rot_key_prep = true;
     }
+    if (key_prepared && !rot_in_tail) {
+        const uint64_t* one[1] = {evk};
+        return tfhe_rotate_many(c, Lk, level, special, one, level, 1, &galois, 1, ct, out, batch);
+    }
+    if (key_prepared) rot_key_prep = false;   // the three-kernel path reads the prepared key where it lies
     // chunk the batch so that the digit tensor stays at a few GiB.  The fused key switches (ks_fused14) never write the digit
     // rows: at N = 2^15 the "digit" buffer only carries the sub-block sums T (2 nw rows per ciphertext), so a whole batch is one
     // launch (cfg#3, 512 ciphertexts: 248 + 248 + 16 before -- the 16 ran as two nearly empty item rounds of k_ks_fused_sub)
@@ -1564,7 +1692,7 @@ static int keyswitch_impl(tfhe_ctx* c, int Lk, int level, int special, const u64
         for (int j = 0; j < level; j++) KA.w.idx[j] = j;
         if (special) KA.w.idx[level] = Lk - 1;
         hipLaunchKernelGGL(k_evk_to_f64, row_grid((unsigned)(level * 2 * nw), N), dim3(256), 0, c->stream, evk, evd, c->limbs_dev, KA, Lk, (u32)N, c->logN <= 14 ? 1 : 0, c->logN == 16 ? 2 : 0,
-                           rot_in_tail ? inv_mod_2n(galois, 2 * (u64)c->N) : (u64)0, 1);
+                           (rot_in_tail && !key_prepared) ? inv_mod_2n(galois, 2 * (u64)c->N) : (u64)0, 1);
         HIP_TRY(hipGetLastError());
     }
     if (rot_key_prep) {
@@ -1685,6 +1813,15 @@ int tfhe_rotate(tfhe_ctx* c, int Lk, int level, int special, const uint64_t* evk
     if (rc) return rc;
     if ((g & 1) == 0) return fail(TFHE_E_BADARG, "galois element must be odd");
     return keyswitch_impl(c, Lk, level, special, evk, ct, 2, out, batch, g, true);
+}
+// the same with the key as tfhe_galois_key_prepare left it (r06): a caller that rotates by ONE Galois element again and again
+// (infer.jl:140-149: 63 chained rotations per matrix product, one key) prepares it once instead of once per call
+int tfhe_rotate_prepared(tfhe_ctx* c, int Lk, int level, int special, const uint64_t* evk_prepared, int n_digits, uint64_t g, const uint64_t* ct, uint64_t* out,
+                         int64_t batch) {
+    int rc = ks_check(c, Lk, level, special, evk_prepared, n_digits, ct, 2, out, batch);
+    if (rc) return rc;
+    if ((g & 1) == 0 || g >= 2 * (u64)c->N) return fail(TFHE_E_BADARG, "galois element must be odd and below 2N");
+    return keyswitch_impl(c, Lk, level, special, evk_prepared, ct, 2, out, batch, g, true, false, true);
 }
 
 // ---- diagonal matrix-vector product (infer.jl:140-149, test/ckks_matmul.jl:33-41) in one call ---------------------------

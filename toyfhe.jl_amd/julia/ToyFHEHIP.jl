@@ -44,7 +44,7 @@ function check(rc::Cint)
     rc in (-3, -4) && throw(ToyFHE.UsageError(msg))     # rlwe_she.jl:223-225,233-235,248-250
     rc == -7 && error(msg)                              # crt.jl:270,274
     if rc == -5                                         # TFHE_E_NOMEM: give the key caches back before the caller sees it (a retry may fit)
-        release_key_caches!(); throw(OutOfMemoryError())
+        release_key_caches!(all=isempty(PREPARED_KEYS)); throw(OutOfMemoryError())   # prepared copies first; the packed keys only when none were left
     end
     error("HIP: " * msg)
 end
@@ -262,7 +262,24 @@ function lincomb_many(scalars::Vector{<:Vector}, as::Vector{<:DevVec{T}}) where 
                 ctx.handle, flat, ap, nterms, dp, nout, cnt, limbs, C_NULL))
     [OffsetArray(d, axes(as[1])...) for d in dsts]
 end
-lincomb(scalars::Vector, as::Vector{<:DevVec{T}}) where {T<:CRTEncoded} = lincomb_many([scalars], as)[1]
+# sum_k scalars[k] .* as[k] in one pass (tfhe_lincomb; r06: bound directly -- it was reached through lincomb_many with one row):
+# per term one scalar_mul (pow2_cyc_rings.jl:177-185) and one + (:200-214) in the reference, the same canonical residues here
+function lincomb(scalars::Vector, as::Vector{<:DevVec{T}}) where {T<:CRTEncoded}
+    @assert !isempty(as)
+    xs = HipVector{T}[a.parent for a in as]; nterms = length(xs)
+    length(scalars) == nterms || throw(AssertionError("lincomb: one scalar per operand"))
+    cnt = xs[1].count; limbs = xs[1].limbs; n = xs[1].n
+    for x in xs
+        samecount(x, xs[1])
+    end
+    flat = UInt64[convert(Integer, c) for s in scalars for c in convert(T, s).c]                      # [nterms][limbs]
+    dst = HipVector{T}(limbs, n, cnt); ctx = on(modring(T, n), (dst,), (xs...,))
+    ap = Ptr{UInt64}[x.ptr for x in xs]
+    GC.@preserve xs dst check(ccall((:tfhe_lincomb, lib), Cint,
+                (Ptr{Cvoid}, Ptr{UInt64}, Ptr{Ptr{UInt64}}, Cint, Ptr{UInt64}, Int64, Cint, Ptr{Int32}),
+                ctx.handle, flat, ap, nterms, dst.ptr, cnt, limbs, C_NULL))
+    OffsetArray(dst, axes(as[1])...)
+end
 
 # ---- K6/K7: modswitch / modswitch_drop / crtselect (crt.jl:185-236) --------------------------------------------------
 function ToyFHE.modswitch(re::RingElement{â„›,T,S}) where {â„›,T<:CRTEncoded,S<:HipVector{T}}
@@ -355,11 +372,17 @@ function prepared(gk::ToyFHE.GaloisKey)
         out
     end
 end
-function release_key_caches!()
+# out-of-memory recovery (check): the PREPARED copies go first (they are re-made from the packed keys by one permutation pass);
+# `all = true` drops the packed keys too.  The dropped vectors are long-lived, old-generation objects: an incremental collection
+# would not reach them, so a FULL collection runs their finalizers (tfhe_free: parked, then reusable) -- and only theirs if no
+# other task still holds one for a call it is about to make (no explicit finalize: that would free under such a caller) (r06,
+# ADVICE r05).
+function release_key_caches!(; all::Bool=false)
     lock(KEY_LOCK) do
-        empty!(PACKED_KEYS); empty!(PREPARED_KEYS); empty!(PREPARED_ORDER); PREPARED_BYTES[] = 0
+        empty!(PREPARED_KEYS); empty!(PREPARED_ORDER); PREPARED_BYTES[] = 0
+        all && empty!(PACKED_KEYS)
     end
-    GC.gc(false)                                       # run the HipVector finalizers (tfhe_free: parked, then reusable)
+    GC.gc(true)
     ccall((:tfhe_alloc_trim, lib), Cint, ())
     nothing
 end
@@ -427,7 +450,18 @@ function ToyFHE.rotate(gk::ToyFHE.GaloisKey, c::CipherText{Enc,P,<:RingElement{â
     @assert length(c.cs) == 2
     ek = gk.key; ToyFHE.relin_window(ek.params) != 0 && return ToyFHE.keyswitch(ek, ToyFHE.NTT.apply_galois_element(c, gk.galois_element))
     keyring = NTT.ring(ek.key[1].mask); Lk = nlimbs(eltype(keyring)); level = nlimbs(T); cnt = batchsize(c)
-    ctx = hipring(keyring); key = pack(ek); ct = pack(ctx, c); out = HipVector{T}(2 * level, degree(â„›), cnt); on(ctx, (out,), (ct, key))
+    ctx = hipring(keyring); ct = pack(ctx, c); out = HipVector{T}(2 * level, degree(â„›), cnt)
+    if degree(â„›) >= 2^15 && cnt >= 8
+        # the rotation is finished in the key switch's tail on the key as tfhe_galois_key_prepare leaves it: prepared once per key
+        # (PREPARED_KEYS), not once per call -- infer.jl:140-149 rotates by ONE key 63 times per matrix product (r06)
+        key = prepared(gk); on(ctx, (out,), (ct, key))
+        GC.@preserve key ct out check(ccall((:tfhe_rotate_prepared, lib), Cint,
+                    (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{UInt64}, Cint, UInt64, Ptr{UInt64}, Ptr{UInt64}, Int64),
+                    ctx.handle, Lk, level, ek.params isa ModulusRaised ? 1 : 0, key.ptr, length(ek.key),
+                    gk.galois_element, ct.ptr, out.ptr, cnt))
+        return CipherText{Enc}(c.params, unpack(ctx, out, â„›, 2))
+    end
+    key = pack(ek); on(ctx, (out,), (ct, key))
     GC.@preserve key ct out check(ccall((:tfhe_rotate, lib), Cint,
                 (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{UInt64}, Cint, UInt64, Ptr{UInt64}, Ptr{UInt64}, Int64),
                 ctx.handle, Lk, level, ek.params isa ModulusRaised ? 1 : 0, key.ptr, length(ek.key),

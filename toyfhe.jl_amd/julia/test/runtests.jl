@@ -67,6 +67,25 @@ end
     end
 end
 
+# ---- scalar-weighted sums in one pass (tfhe_lincomb / tfhe_lincomb_many; examples/encrypted_mnist/infer.jl:127-131) -----------
+@testset "lincomb: sum_k w_k .* a_k against scalar_mul and + (pow2_cyc_rings.jl:177-185, 200-214)" begin
+    n = 2^6
+    ℛ = rns_ring(n, chain(Int128(2)^40 + 1, 3, n))
+    rng = MersenneTwister(3)
+    as = [rand(rng, ToyFHE.RingSampler(ℛ, ToyFHE.DiscreteUniform(ToyFHE.NTT.coefftype(ℛ)))) for _ in 1:5]
+    das = map(dev, as)
+    ws = [3, 70000, 1, 2^33 + 5, 12]
+    want = sum(w * a for (w, a) in zip(ws, as))
+    got = H.lincomb(ws, [coeffs_primal(x) for x in das])
+    @test residues(want) == [UInt64[convert(Integer, x) for x in col] for col in StructArrays.fieldarrays(H.download(got.parent))]
+    rows = [ws, reverse(ws)]
+    gots = H.lincomb_many(rows, [coeffs_primal(x) for x in das])
+    for (row, g) in zip(rows, gots)
+        w2 = sum(w * a for (w, a) in zip(row, as))
+        @test residues(w2) == [UInt64[convert(Integer, x) for x in col] for col in StructArrays.fieldarrays(H.download(g.parent))]
+    end
+end
+
 # ---- BFV over RNS with a disjoint extension basis (test/bfv_crt.jl:8-47) ------------------------------------------------------
 @testset "bfv_crt: enc_mul, multround / switch (src/bfv.jl:34-40, 172-226)" begin
     n = 2048

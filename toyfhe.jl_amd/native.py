@@ -120,6 +120,7 @@ def lib():
         "tfhe_galois": [vp, vp, vp, u64, i64, i32, i32p],
         "tfhe_keyswitch": [vp, i32, i32, i32, vp, i32, vp, i32, vp, i64],
         "tfhe_rotate": [vp, i32, i32, i32, vp, i32, u64, vp, vp, i64],
+        "tfhe_rotate_prepared": [vp, i32, i32, i32, vp, i32, u64, vp, vp, i64],
         "tfhe_keyswitch_window": [vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i64],
         "tfhe_rotate_many": [vp, i32, i32, i32, C.POINTER(vp), i32, i32, u64p, i32, vp, vp, i64],
         "tfhe_galois_key_prepare": [vp, i32, i32, u64, vp, vp],
@@ -157,7 +158,7 @@ EXPORTED_SYMBOLS = [
     "tfhe_ctx_set_stream", "tfhe_ctx_sync", "tfhe_ctx_wait_for", "tfhe_ctx_set_ntt_variant", "tfhe_malloc", "tfhe_free", "tfhe_memcpy_h2d",
     "tfhe_memcpy_d2h", "tfhe_memcpy_d2d", "tfhe_memset", "tfhe_pack_poly", "tfhe_unpack_poly", "tfhe_broadcast_poly", "tfhe_alloc_stats", "tfhe_alloc_trim", "tfhe_comm_id", "tfhe_comm_create", "tfhe_comm_destroy", "tfhe_gather", "tfhe_nntt", "tfhe_inntt", "tfhe_add", "tfhe_sub", "tfhe_neg",
     "tfhe_mul", "tfhe_mad", "tfhe_dot", "tfhe_scalar_mul", "tfhe_tensor", "tfhe_rescale", "tfhe_select_limbs", "tfhe_galois",
-    "tfhe_keyswitch", "tfhe_rotate", "tfhe_rotate_many", "tfhe_galois_key_prepare", "tfhe_matmul_diag", "tfhe_lincomb", "tfhe_lincomb_many", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
+    "tfhe_keyswitch", "tfhe_rotate", "tfhe_rotate_prepared", "tfhe_rotate_many", "tfhe_galois_key_prepare", "tfhe_matmul_diag", "tfhe_lincomb", "tfhe_lincomb_many", "tfhe_keyswitch_window", "tfhe_ckks_encode", "tfhe_ckks_decode", "tfhe_sample_uniform", "tfhe_sample_gaussian", "tfhe_bfv_plan_create", "tfhe_bfv_plan_destroy", "tfhe_bfv_plan_set_chunk",
     "tfhe_bfv_plan_set_variant", "tfhe_bfv_mul", "tfhe_bfv_expand", "tfhe_bfv_contract", "tfhe_bfv_mul_relin", "tfhe_prof_enable", "tfhe_prof_read",
     "tfhe_event_create", "tfhe_event_destroy", "tfhe_event_record", "tfhe_event_elapsed_ms",
 ]
@@ -366,8 +367,9 @@ class Context:
     def ckks_decode(self, level, scale_mant, scale_exp2, src, slots, batch):
         check(lib().tfhe_ckks_decode(self.h, level, int(scale_mant), int(scale_exp2), src, slots, batch))
 
-    def rotate(self, key_limbs, level, special, evk, n_digits, g, ct, out, batch):
-        check(lib().tfhe_rotate(self.h, key_limbs, level, int(bool(special)), evk, n_digits, int(g), ct, out, batch))
+    def rotate(self, key_limbs, level, special, evk, n_digits, g, ct, out, batch, prepared=False):
+        f = lib().tfhe_rotate_prepared if prepared else lib().tfhe_rotate
+        check(f(self.h, key_limbs, level, int(bool(special)), evk, n_digits, int(g), ct, out, batch))
 
     def rotate_many(self, key_limbs, level, special, evks, n_digits, gs, ct, out, batch, prepared=False):
         ptrs = (C.c_void_p * len(evks))(*[int(p) for p in evks])

@@ -342,11 +342,17 @@ class CipherText:
         self._packed_image = (image, ctx, tuple(x.primal for x in self.cs))
         return self
 
-    def _packed_for(self, prim, ctx):
-        """the packed image of exactly these coefficient buffers on this context, or None"""
+    def _packed_for(self, prim, ctx, consume=False):
+        """the packed image of exactly these coefficient buffers on this context, or None.  ``consume``: the image is handed
+        over and forgotten (r06, ADVICE r05: a result ciphertext otherwise holds its packed buffer next to the unpacked
+        components -- twice the device memory -- for as long as it lives; a chained caller uses it exactly once)"""
         pi = self._packed_image
         if pi is not None and pi[1] is ctx and len(pi[2]) == len(prim) and all(a is b for a, b in zip(pi[2], prim)):
+            if consume:
+                self._packed_image = None
             return pi[0]
+        if consume:
+            self._packed_image = None      # stale (a component was replaced): nothing can use it any more
         return None
 
     def __len__(self):
@@ -734,7 +740,7 @@ def keygen_galois(rng, priv: PrivKey, galois_element=None, steps=None) -> Galois
     return GaloisKey(galois_element, make_eval_key(rng, priv.secret.apply_galois_element(galois_element), priv))
 
 
-def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
+def keyswitch(ek, c: CipherText, _galois=None, _gk=None) -> CipherText:
     """keyswitch(ek, c), rlwe_she.jl:315-349 -- one fused device call."""
     if isinstance(ek, (EvalMultKey, GaloisKey)):
         ek = ek.key
@@ -773,10 +779,15 @@ def keyswitch(ek, c: CipherText, _galois=None) -> CipherText:
     prim = [x.coeffs_primal() for x in c.cs]               # may enqueue inverse transforms on the ciphertext ring's stream ...
     if ring.ctx is not keyring.ctx:
         keyring.ctx.wait_for(ring.ctx)                     # ... so the hand-over to the key ring's stream comes after them
-    ct = c._packed_for(prim, keyring.ctx) or _pack(prim, ring, n, ctx=keyring.ctx)
+    ct = c._packed_for(prim, keyring.ctx, consume=True) or _pack(prim, ring, n, ctx=keyring.ctx)
     out = DeviceBuffer(n * 2 * sz)
     if _galois is None:
         keyring.ctx.keyswitch(keyring.L, level, special, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n)
+    elif _gk is not None and ring.N >= (1 << 15) and n >= 8:
+        # N >= 2^15, 8 ciphertexts or more: the rotation is finished in the key switch's tail on the key as
+        # tfhe_galois_key_prepare leaves it -- prepared once per key (GaloisKey.prepared), not once per call (r06:
+        # infer.jl:140-149 rotates by ONE key 63 times per matrix product)
+        keyring.ctx.rotate(keyring.L, level, special, _gk.prepared().ptr, len(ek.key), _galois, ct.ptr, out.ptr, n, prepared=True)
     else:
         keyring.ctx.rotate(keyring.L, level, special, ek.packed().ptr, len(ek.key), _galois, ct.ptr, out.ptr, n)
     cs = _unpack(out, ring, n, 2, batch, primal=True, ctx=keyring.ctx)
@@ -793,7 +804,7 @@ def rotate(gk: GaloisKey, c: CipherText) -> CipherText:
     """rotate(gk, c) = keyswitch(gk, apply_galois_element(c, g)), rlwe_she.jl:359 (fused on the device)."""
     if len(c) != 2:
         raise AssertionError("rotate takes a 2-element ciphertext")
-    return keyswitch(gk.key, c, _galois=gk.galois_element)
+    return keyswitch(gk.key, c, _galois=gk.galois_element, _gk=gk)
 
 
 def rotate_many(gks, c: CipherText):
