@@ -161,6 +161,9 @@ def _compact_config(c):
         if r:
             out.setdefault("kern", {})[op] = [str(r.get("kernel", "")).replace(" ", "")[:36], r.get("bound"), _r(r.get("frac"), 3),
                                               _r(r.get("traffic_over_algorithmic"), 3)]          # kernel, bound, frac, traffic / algorithmic
+            ts = r.get("traffic_split")
+            if ts:                                                    # ... of which key rows (cache-served, counted) / streaming rows (calibrated)
+                out["kern"][op] += [_r(ts.get("key_over_algorithmic"), 3), _r(ts.get("rows_over_algorithmic"), 3)]
     if (c.get("roofline_source") or {}).get("pmc_stale"):
         out["pmc_stale"] = True
     return out
@@ -213,6 +216,24 @@ def compact_line(result, limit=LINE_LIMIT):
         if len(json.dumps(line)) < limit:
             break
         step()
+    # the guarantee, enforced: the unbounded parts that survive every step above (config extras, roofline, cpu_baseline)
+    # go next, last of all everything but the contract keys with the strings cut -- an oversized line is what the driver truncates
+    for k in ("full_record", "cpu_baseline", "roofline"):
+        if len(json.dumps(line)) < limit:
+            break
+        if k == "roofline" and isinstance(line.get(k), dict):
+            line[k] = {f: line[k][f] for f in ("bound", "achieved", "peak", "unit", "frac", "traffic") if f in line[k]}
+        elif k == "cpu_baseline" and isinstance(line.get(k), dict):
+            line[k] = {f: line[k][f] for f in ("value", "unit", "cores", "kind") if f in line[k]}
+        else:
+            line.pop(k, None)
+    if len(json.dumps(line)) >= limit:
+        cfgw = str((line.get("config") or {}).get("workload", ""))[:80]
+        line = {k: (v if not isinstance(v, str) else v[:60]) for k, v in line.items()
+                if k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+        line["config"] = {"workload": cfgw}
+        line["truncated"] = True
+    assert len(json.dumps(line)) < limit or limit < 600, "compact_line: contract keys alone exceed the limit"
     return line
 
 
@@ -346,16 +367,16 @@ def main():
               full = torch.empty(world * flat.numel(), dtype=flat.dtype, device=dev)
           if args.backend == "nccl" and args.cabi_gather:
               try:                                                       # the library's own communicator; a failure is a one-line reason, not a lost leg
-                  comm = tdist.make_comm()                               # tfhe_comm_create over the same ranks
-                  run_gather = lambda: comm.gather(ctx, flat.data_ptr(), full.data_ptr(), flat.numel())
-                  run_gather()
-                  torch.cuda.synchronize()
+                  comm = tdist.make_comm()                               # tfhe_comm_create over the same ranks (rendezvous with a deadline)
               except Exception as e:                                     # noqa: BLE001
-                  comm, run_gather, fallback = None, None, f"tfhe_comm_create / tfhe_gather: {type(e).__name__}: {e}"[:160]
-              # every rank must take the same branch: one rank's failure sends all to torch's collective
+                  comm, fallback = None, f"tfhe_comm_create: {type(e).__name__}: {e}"[:160]
+              # every rank must take the same branch BEFORE the first collective on the communicator is issued (a rank
+              # that failed to create it would leave the others waiting inside tfhe_gather): one rank's failure sends all to torch's
               ok_all = tdist.max_over_ranks(0.0 if comm is not None else 1.0, device=coll_dev) == 0.0
               if not ok_all and comm is not None:
-                  comm, run_gather, fallback = None, None, "tfhe_comm_create failed on another rank"
+                  comm, fallback = None, "tfhe_comm_create failed on another rank"
+              if comm is not None:
+                  run_gather = lambda: comm.gather(ctx, flat.data_ptr(), full.data_ptr(), flat.numel())
           if run_gather is None and args.backend == "nccl":
               run_gather = lambda: dist.all_gather_into_tensor(full, flat)
           elif run_gather is None:

@@ -68,6 +68,28 @@ def test_line_stays_below_the_limit_whatever_the_record_holds():
         assert k in back, k                                              # what is dropped to fit is never the contract
 
 
+def test_line_with_oversized_unbounded_parts_is_forced_to_fit():
+    """config extras, a plain roofline dict and the cpu_baseline survive every ordinary shrink step; the fit is enforced
+    after them -- first their extras go, last of all everything but the contract keys."""
+    full = canned()
+    full["config"] = dict(full["config"], **{f"extra_{i}": "k" * 300 for i in range(40)})
+    line = bench.compact_line(full)
+    s = json.dumps(line)
+    assert len(s) < 4096
+    back = json.loads(s)
+    for k in CONTRACT:
+        assert k in back, k
+    assert back.get("truncated") is True and "workload" in back["config"]
+    # a roofline of many scalar fields (the non-headline form) alone: its six contract fields stay
+    full = canned()
+    full["roofline"] = dict({"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None},
+                            **{f"n{i}": "r" * 79 for i in range(80)})
+    back = json.loads(json.dumps(bench.compact_line(full)))
+    assert len(json.dumps(back)) < 4096 and back["roofline"]["frac"] == 0.1 and "n0" not in back["roofline"]
+    for k in CONTRACT + ("roofline",):
+        assert k in back, k
+
+
 def test_emit_prints_the_compact_line_last_on_stdout_and_the_full_record_elsewhere(tmp_path, monkeypatch):
     full = canned()
     monkeypatch.setattr(bench, "FULL_RECORD", str(tmp_path / "bench_full.json"))

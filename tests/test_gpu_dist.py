@@ -173,3 +173,38 @@ def test_bench_multi_rank_modes_of_the_other_configurations(cfg, total, units):
     assert res["scaling"] == ("weak" if cfg == "cfg3" else "strong")
     if cfg != "cfg5":
         assert res["gather"] and "error" not in res["gather"] and res["gather"]["value_with_gather"] <= res["value"] * 1.0001
+
+
+@pytest.mark.parametrize("mode,extra,units", [
+    ("bfv", ["--batch", "8", "--no-cpu", "--no-ntt", "--no-configs"], [8] * 8),
+    ("cfg4", ["--total", "4096"], [512] * 8),                                  # BASELINE configs[3] as it is defined: 4096 -> 8 x 512
+    ("cfg5", ["--total", "10000"], [3, 3, 3, 3, 2, 2, 2, 2]),                  # configs[4]: 20 ciphertext sets of 512 images
+])
+def test_eight_rank_rehearsal(mode, extra, units):
+    """the world = 8 code paths (sharding, per-rank records, agreement on errors, the compact line of an 8-rank
+    record, the gather leg) run BEFORE they meet eight physical GPUs.  Eight GPUs visible: one rank each over RCCL; fewer: all ranks on
+    the devices there are over gloo (functional: the rates mean nothing).  Every rank checks a ciphertext of its own shard against the
+    oracle before the timed region (bench.py / bench_configs._multi_setup) -- the union of the shards is the global batch by
+    construction of dist.shard (tests/test_dist_cpu.py)."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 8 else "gloo"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--backend", backend] + extra
+    if mode != "bfv":
+        cmd += ["--config", mode]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line, res = _line_and_record(out)                                          # one stdout line, < 4 KB, equal to the full record on disk
+    assert "error" not in res and not res.get("errors"), res
+    assert line["n_gpus"] == 8 and line["nranks_seen"] == 8 and line["value"] > 0 and res["nranks_seen"] == 8
+    if mode == "bfv":
+        assert line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
+        assert res["gather"] and "error" not in res["gather"]
+        return
+    key = "sets" if mode == "cfg5" else "units"
+    assert [r[key] for r in res["per_rank"]] == units and [r["rank"] for r in res["per_rank"]] == list(range(8))
+    assert res["scaling"] == "strong" and res["global_units"] == (4096 if mode == "cfg4" else 20 * 512)
+    assert res["imbalance_max_over_min"] >= 1.0
+    if mode == "cfg4":
+        assert res["gather"] and "error" not in res["gather"]

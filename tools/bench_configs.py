@@ -392,6 +392,16 @@ def attach_rooflines(records):
                 e["traffic"] = pc["hbm_bytes"] / b                                    # HBM-side bytes per unit (all kernels of the operation)
                 e["algorithmic_bytes"] = alg[op]
                 e["traffic_over_algorithmic"] = e["traffic"] / alg[op]
+                if op == "main" and str(pc["dominant"]).startswith("k_ks_fused"):
+                    # what the ratio is made of.  A fused key switch reads, per (ciphertext, working limb) item, the
+                    # key words of every digit for that limb (doubles, both components): level x 2 x nw rows of N words per ciphertext.
+                    # The 32-128 MiB of key rows of a call are shared by all items and are served by the L2s / the Infinity Cache --
+                    # FETCH_SIZE counts those hits like HBM reads.  The rest (digit source rows, sub-block sums, results) streams and is
+                    # what the x2 calibration of FETCH_SIZE was made on.
+                    nw = r["level"] + (1 if r.get("special_prime", True) else 0)
+                    keyb = float(r["level"] * 2 * nw * r["N"] * 8)
+                    e["traffic_split"] = {"key_rows_bytes_cache_served_counted": keyb, "row_bytes_streaming_calibrated": max(0.0, e["traffic"] - keyb),
+                                          "key_over_algorithmic": keyb / alg[op], "rows_over_algorithmic": max(0.0, e["traffic"] - keyb) / alg[op]}
             roofs["keyswitch" if (op == "main" and "level" in r) else ("pass" if op == "main" else op)] = e
         if roofs:
             r["roofline"] = roofs

@@ -168,4 +168,13 @@ else:
                   f"{g('hbm_frac', '%8.3f'):>8s} {g('valu_per_wave', '%9.0f'):>9s} {g('SQ_WAIT_ANY_share', '%5.2f'):>5s} "
                   f"{g('SQ_WAIT_INST_ANY_share', '%5.2f'):>5s} {g('SQ_ACTIVE_INST_ANY_share', '%5.2f'):>5s} {e.get('bound', ''):>5s}"
                   + ("  (bytes uncalibrated: gather / scatter)" if "byte_calibration" in e else ""))
+        rec_, pm = cv.get("record") or {}, (cv.get("per_call") or {}).get("main")
+        if pm and "level" in rec_ and str(pm.get("dominant", "")).startswith("k_ks_fused"):
+            # what the traffic ratio of a fused key switch is made of: key rows are shared by all items of a call and
+            # come from the L2s / the Infinity Cache (FETCH_SIZE counts the hits); the rest streams (what the x2 calibration was made on)
+            lv, n_, b_ = rec_["level"], rec_["N"], rec_.get("batch") or 1
+            alg, keyb, tot = 4 * lv * n_ * 8, lv * 2 * (lv + 1) * n_ * 8, pm["hbm_bytes"] / b_
+            print(f"   per key switch (key switch + rotation calls averaged): HBM-side {tot / 1e6:.1f} MB = {tot / alg:.1f} x the algorithmic {alg / 1e6:.1f} MB: "
+                  f"key rows {keyb / 1e6:.1f} MB ({keyb / alg:.1f} x; cache-served, counted) + rows {max(0.0, tot - keyb) / 1e6:.1f} MB "
+                  f"({max(0.0, tot - keyb) / alg:.1f} x; streaming, calibrated)")
         print()
