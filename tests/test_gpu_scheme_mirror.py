@@ -381,6 +381,42 @@ def test_dot_plain_equals_the_sum_of_plaintext_products():
         tf.CipherText.dot_plain(cts, pts[:-1] + [tf.ckks_encode(wts[0], R, scale)])      # a plaintext of another ring
 
 
+@pytest.mark.parametrize("logn,bits", [(11, (40, 40, 40, 40)), (13, (60, 40, 40, 61))])
+def test_dot_plain_batches_the_forward_transforms_of_its_operands(monkeypatch, logn, bits):
+    """r06: dot_plain stages operands that are still in the coefficient domain side by side and transforms them in one call per
+    chunk (infer.jl:140-149's 63 rotated ciphertexts, 16 polynomials each, are quarter-chip launches one by one).  Same words as
+    one transform per element, with one chunk, with several, and with elements whose transform is already cached in between."""
+    N = 1 << logn
+    qs = []
+    for b in bits:
+        qs += [q for q in chain(2**b + 1, 4, N) if q not in qs][:1]
+    R = tf.NegacyclicRing(N, qs)
+    rng = np.random.default_rng(77)
+    K, B = 7, 3
+    mk = lambda: tf.RingElement(R, tf.DeviceBuffer.from_numpy(np.stack([rng.integers(0, q, size=(B, N), dtype=np.uint64) for q in qs], axis=1)), None, B)
+    params = tf.CKKSParams(R, 0, 3.2)
+    fresh = lambda els: [tf.RingElement(R, e.primal, None, B) for e in els]
+    a0, a1 = [mk() for _ in range(K)], [mk() for _ in range(K)]
+    pts = [mk() for _ in range(K)]
+    for p_ in pts:
+        p_.coeffs_dual()
+
+    def run(pre=()):
+        e0, e1 = fresh(a0), fresh(a1)
+        for i in pre:
+            e0[i].coeffs_dual()                                         # cached transforms are used where they lie
+        cts = [tf.CipherText(params, (x, y), 2**40) for x, y in zip(e0, e1)]
+        r = tf.CipherText.dot_plain(cts, pts)
+        return [c.to_numpy("dual") for c in r.cs]
+    monkeypatch.setattr(tf.she, "_BATCH_NTT_MAX_WORDS", 0)
+    want = run()                                                        # one transform per element
+    monkeypatch.setattr(tf.she, "_BATCH_NTT_MAX_WORDS", 1 << 25)
+    for chunk, pre in ((1 << 29, ()), (2 * B * len(qs) * N, ()), (3 * B * len(qs) * N, (0, 4))):
+        monkeypatch.setattr(tf.she, "_BATCH_NTT_CHUNK_WORDS", chunk)
+        got = run(pre)
+        assert all(np.array_equal(g, w) for g, w in zip(got, want)), (chunk, pre)
+
+
 def test_ckks_mul_rescale_pipeline():
     """the encrypted_mnist-style step: ct*ct -> relinearise (special prime) -> rescale."""
     N = 64

@@ -2287,6 +2287,9 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                         for (int m = 0; m < (1 << X); m++) {
 #ifdef TFHE_ABL_NOROWS  // design aid: operands from arithmetic (wrong results, no row traffic)
                             q[m][r] = (u64)(k * 131u + (u32)m * 7919u) + (u64)(size_t)grow; pin_vgpr(q[m][r]);
+#elif defined(TFHE_ABL_TOPONCE)  // design aid (r06, wrong results): a sub-block workgroup loads and lifts ONE of the row's 2^X parts and
+                            // pays no top-stage product -- the upper bound of "the top stage paid once per row" 
+                            if (m == 0) q[m][r] = grow[k + ((sb & ((1u << X) - 1u)) << LOGB)];
 #else
                             q[m][r] = grow[k + ((u32)m << LOGB)];
 #endif
@@ -2296,6 +2299,9 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
 #pragma unroll
                     for (int r = 0; r < PE; r++) {
                         // loosely lifted digits (|v| <= p): sums <= 1.88 p, products <= 1.21 p, <= 3.09 p before the reduction
+#ifdef TFHE_ABL_TOPONCE
+                        const double z = A::from_global_lift(q[0][r], C, lf, true);
+#else
                         double xin[1 << X];
 #pragma unroll
                         for (int m = 0; m < (1 << X); m++) xin[m] = A::from_global_lift(q[m][r], C, lf, true);
@@ -2307,6 +2313,7 @@ __global__ __launch_bounds__(1 << LOGT) void k_ks_fused_sub(const u64* __restric
                             const double yb = fp_fma(sgn_h, fp_mulmod_c(xin[3], w1, C.p, C.pinv), xin[1]);
                             z = fp_fma(sgn_q, fp_mulmod_c(yb, w2, C.p, C.pinv), ya);
                         }
+#endif
                         op[h * PE + r] = A::to_lds(A::top_reduce(z, C));
                     }
                     TFHE_SCHED_FENCE();

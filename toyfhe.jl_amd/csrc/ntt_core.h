@@ -466,6 +466,36 @@ TFHE_HD void fwd_load_tw(typename A::tw* tw, const typename A::ctx& C, u32 tid, 
                                                         : A::ld_fwd(C, (pre << (S0 + d)) + (hi << d) + (u32)g);
     }
 }
+// Design aid (r06, wrong results by design): -DTFHE_ABL_NOXCHG=<bits> takes the pass-to-pass exchange out of every transform so that
+// its share of a fused kernel's time can be MEASURED (profiles/LOG.md round 6): bit 0 -- __syncthreads() becomes a compiler barrier (no
+// s_barrier, the waits on the LDS counters stay where the data dependences put them); bit 1 -- the LDS reads / writes between two
+// passes are replaced by register pins (the address arithmetic stays: the "read" returns its own address); bit 2 -- only the writes;
+// bit 3 -- only the reads.  Same butterflies, same global loads and stores.  (r06: with bit 1 or bit 3 the fused kernels leave their
+// zero-scratch allocation -- 168-412 B -- and run 22 % SLOWER: the builds bound nothing; bit 0 and bit 2 keep the allocation.)
+#ifndef TFHE_ABL_NOXCHG
+#define TFHE_ABL_NOXCHG 0
+#endif
+#if (TFHE_ABL_NOXCHG & 1) && defined(__HIP_DEVICE_COMPILE__)
+#define __syncthreads() asm volatile("" ::: "memory")
+#endif
+TFHE_HD u64 xchg_rd(const u64* lds, u32 i) {
+#if (TFHE_ABL_NOXCHG & (2 | 8)) && defined(__HIP_DEVICE_COMPILE__)
+    u64 r = (u64)i;   // (not the pointer: a generic address of the LDS array costs an aperture test per read)
+    (void)lds;
+    asm volatile("" : "+v"(r));
+    return r;
+#else
+    return lds[i];
+#endif
+}
+TFHE_HD void xchg_wr(u64* lds, u32 i, u64 v) {
+#if (TFHE_ABL_NOXCHG & (2 | 4)) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v), "v"(i));
+    (void)lds;
+#else
+    lds[i] = v;
+#endif
+}
 // raw 64-bit words of the operands (global: residues; LDS: the policy's element bits)
 template <int LOGB, int LOGT, int S0, int K, bool FIRST, bool LAST, int USEL = -1>
 TFHE_HD void fwd_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, const lift_t* lift = nullptr) {
@@ -479,7 +509,7 @@ TFHE_HD void fwd_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, c
 #pragma unroll
         for (int r = 0; r < G::R; r++) {
             const u32 j = base + ((u32)r << G::LO);
-            raw[u * G::R + r] = FIRST ? gsrc[j] : lds[pb + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)];
+            raw[u * G::R + r] = FIRST ? gsrc[j] : xchg_rd(lds, pb + lds_phi_c<LOGB, LOGT>((u32)r << G::LO));
         }
     }
     TFHE_SCHED_FENCE();  // every operand is requested before the first butterfly (no just-in-time read/wait pairs)
@@ -534,8 +564,8 @@ TFHE_HD void fwd_compute(typename A::elem* v, const u64* raw, const typename A::
                     A::bf_fwd(vv[r0], vv[r0 + half], w, C);
                     if (!LAST && lds_early && d == K - 1) {   // (half == 1: r0 and r0 + 1 are final)
                         const u32 pb = lds_phi<LOGB, LOGT>(base);
-                        lds_early[pb + lds_phi_c<LOGB, LOGT>((u32)r0 << G::LO)] = A::to_lds(vv[r0]);
-                        lds_early[pb + lds_phi_c<LOGB, LOGT>((u32)(r0 + 1) << G::LO)] = A::to_lds(vv[r0 + 1]);
+                        xchg_wr(lds_early, pb + lds_phi_c<LOGB, LOGT>((u32)r0 << G::LO), A::to_lds(vv[r0]));
+                        xchg_wr(lds_early, pb + lds_phi_c<LOGB, LOGT>((u32)(r0 + 1) << G::LO), A::to_lds(vv[r0 + 1]));
                     }
                 }
                 hook(((u * K + d) * (G::R / 2)) + g * half, ((u * K + d) * (G::R / 2)) + (g + 1) * half, G::SETS * K * (G::R / 2));
@@ -560,7 +590,7 @@ TFHE_HD void fwd_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
                 const u32 nat = (brev_bits((u32)r, K) << (LOGB - K)) + c0;  // brv_LOGB(block-local position)
                 gdst[((u64)nat << x) + sb_rev] = A::out_fwd(e, C);
             } else {
-                lds[pb + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)] = A::to_lds(e);  // lazy (the range plan spans the passes)
+                xchg_wr(lds, pb + lds_phi_c<LOGB, LOGT>((u32)r << G::LO), A::to_lds(e));  // lazy (the range plan spans the passes)
             }
         }
     }
@@ -609,7 +639,7 @@ TFHE_HD void inv_load_data(u64* raw, const u64* lds, const u64* gsrc, u32 tid, i
                 const u32 nat = (brev_bits((u32)r, K) << (LOGB - K)) + c0;
                 raw[u * G::R + r] = gsrc[((u64)nat << x) + sb_rev];
             } else {
-                raw[u * G::R + r] = lds[lds_phi<LOGB, LOGT>(base) + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)];
+                raw[u * G::R + r] = xchg_rd(lds, lds_phi<LOGB, LOGT>(base) + lds_phi_c<LOGB, LOGT>((u32)r << G::LO));
             }
         }
     }
@@ -689,8 +719,8 @@ TFHE_HD void inv_compute(typename A::elem* v, const u64* raw, const typename A::
                             const u32 pb = lds_phi<LOGB, LOGT>(base);
                             typename A::elem e0 = vv[r0], e1 = vv[r0 + half];
                             if (A::template inv_lds_reduce<LOGB, LOGT, S0>()) { A::range_inv(e0, C); A::range_inv(e1, C); }
-                            lds_early[pb + lds_phi_c<LOGB, LOGT>((u32)r0 << G::LO)] = A::to_lds(e0);
-                            lds_early[pb + lds_phi_c<LOGB, LOGT>((u32)(r0 + half) << G::LO)] = A::to_lds(e1);
+                            xchg_wr(lds_early, pb + lds_phi_c<LOGB, LOGT>((u32)r0 << G::LO), A::to_lds(e0));
+                            xchg_wr(lds_early, pb + lds_phi_c<LOGB, LOGT>((u32)(r0 + half) << G::LO), A::to_lds(e1));
                         }
                     }
                 }
@@ -793,7 +823,7 @@ TFHE_HD void inv_store(typename A::elem* v, u64* lds, u64* gdst, const typename 
             for (int r = 0; r < G::R; r++) {
                 typename A::elem e = v[u * G::R + r];
                 if (A::template inv_lds_reduce<LOGB, LOGT, S0>()) A::range_inv(e, C);
-                lds[lds_phi<LOGB, LOGT>(base) + lds_phi_c<LOGB, LOGT>((u32)r << G::LO)] = A::to_lds(e);
+                xchg_wr(lds, lds_phi<LOGB, LOGT>(base) + lds_phi_c<LOGB, LOGT>((u32)r << G::LO), A::to_lds(e));
             }
         }
     }

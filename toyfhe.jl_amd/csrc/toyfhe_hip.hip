@@ -607,6 +607,7 @@ int run_ntt(tfhe_ctx* c, bool inverse, const u64* src, u64* dst, int64_t rows, c
             int rc1 = ensure_ws(c, (size_t)rows * c->N * 8, &tmp);
             if (rc1) return rc1;
             lanes_t lanes(c);
+            // (which policy is enqueued first makes no difference: TFHE_LANE_FP_FIRST A/B, profiles/r06b_lane_order_ab.txt)
             lanes.use(0);   // the u64 launches (top stages + block kernel: the long pole) first, on the main lane
             rc1 = run_ntt_large(c, inverse, src, dst, rows, sel, b, nullptr, false);
             if (rc1) return rc1;

@@ -326,6 +326,45 @@ class GaloisKey:
         return self._prepared
 
 
+# the forward transforms of many ring elements in one launch.  Above this many words a single element's transform fills the chip by itself.
+_BATCH_NTT_MAX_WORDS = 1 << 25
+_BATCH_NTT_CHUNK_WORDS = 1 << 29      # at most 4 GiB of staged coefficients per launch
+
+
+def _dual_ptrs_batched(elems):
+    """Evaluation-domain pointers of ring elements of ONE ring and batch size.  Elements whose transform is not cached yet and
+    that are small against the chip (r06: a batch of 16 ciphertext components at N = 2^16 is 16 rows of a 60-bit limb -- 64 of the 256
+    workgroup slots -- per call; the reference-shaped matrix product of infer.jl:140-149 asks for 2 x 63 such transforms, one per
+    rotated ciphertext) are copied side by side and transformed in ONE call per chunk; the transforms are the same per row, so
+    the values are those of `coeffs_dual()` bit for bit.  Nothing is cached on the elements (the staged buffers go back to the
+    allocator with the returned `keep`).  Returns (pointers, keep-alive list)."""
+    first = elems[0]
+    ring, n = first.ring, first.count
+    words = n * ring.L * ring.N
+    todo = [i for i, e in enumerate(elems) if e.dual is None]
+    ptrs = [None] * len(elems)
+    for i, e in enumerate(elems):
+        if e.dual is not None:
+            ptrs[i] = e.dual.ptr
+    keep = []
+    if len(todo) < 2 or words > _BATCH_NTT_MAX_WORDS:
+        for i in todo:
+            ptrs[i] = elems[i].coeffs_dual().ptr
+        return ptrs, keep
+    per = max(1, _BATCH_NTT_CHUNK_WORDS // words)
+    lib = native.lib()
+    for a in range(0, len(todo), per):
+        part = todo[a:a + per]
+        src, dst = DeviceBuffer(len(part) * words), DeviceBuffer(len(part) * words)
+        for k, i in enumerate(part):
+            native.check(lib.tfhe_memcpy_d2d(ring.ctx.h, src.ptr + k * words * 8, elems[i].coeffs_primal().ptr, words * 8))
+        ring.ctx.nntt(src.ptr, dst.ptr, len(part) * n, ring.L, ring.idx)
+        for k, i in enumerate(part):
+            ptrs[i] = dst.ptr + k * words * 8
+        keep += [src, dst]
+    return ptrs, keep
+
+
 class CipherText:
     """CipherText{Plain,P,T,N}(params, cs), rlwe_she.jl:131-149.  ``scale`` carries the CKKS FixedRational
     denominator (a type parameter upstream, ckksencoding.jl:3-15)."""
@@ -449,9 +488,10 @@ class CipherText:
         pb = [p.coeffs_dual() for p in plains]
         out = []
         for s_ in range(len(c0)):
-            ab = [c.cs[s_].coeffs_dual() for c in cts]
+            ptrs, keep = _dual_ptrs_batched([c.cs[s_] for c in cts])
             o = DeviceBuffer(n * ring.L * ring.N)
-            ring.ctx.dot(None, [x.ptr for x in ab], [x.ptr for x in pb], o.ptr, n, ring.L, ring.idx)
+            ring.ctx.dot(None, ptrs, [x.ptr for x in pb], o.ptr, n, ring.L, ring.idx)
+            del keep      # (released in stream order: the allocator parks a block until the work enqueued so far has finished)
             out.append(RingElement(ring, None, o, batch))
         return CipherText(c0.params, out, Fraction(c0.scale) ** 2)
 
