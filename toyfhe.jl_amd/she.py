@@ -326,43 +326,66 @@ class GaloisKey:
         return self._prepared
 
 
-# the forward transforms of many ring elements in one launch.  Above this many words a single element's transform fills the chip by itself.
-_BATCH_NTT_MAX_WORDS = 1 << 25
-_BATCH_NTT_CHUNK_WORDS = 1 << 29      # at most 4 GiB of staged coefficients per launch
+# the forward transforms of many small ring elements in one launch (CipherText.dot_plain).  Above _BATCH_NTT_MAX_WORDS a single element's
+# transform fills the chip by itself; a chunk stages at most _BATCH_NTT_CHUNK_WORDS (1 GiB) of coefficients, and as much of results.
+_BATCH_NTT_MAX_WORDS = 0 if __import__('os').environ.get('TFHE_BATCH_NTT', '1') == '0' else 1 << 25   # TFHE_BATCH_NTT=0: one transform per element (comparisons)
+_BATCH_NTT_CHUNK_WORDS = 1 << 27
 
 
-def _dual_ptrs_batched(elems):
-    """Evaluation-domain pointers of ring elements of ONE ring and batch size.  Elements whose transform is not cached yet and
-    that are small against the chip (r06: a batch of 16 ciphertext components at N = 2^16 is 16 rows of a 60-bit limb -- 64 of the 256
+def _stage_buffers(ctx, words):
+    """the context's two staging buffers (coefficients in, evaluation-domain rows out), grown on demand and kept for the context's
+    lifetime: everything that touches them is enqueued on the context's own stream, so a chunk may reuse them as soon as the previous
+    chunk's calls are enqueued.  (r06: fresh multi-GiB buffers per call went through the recycling allocator -- past its soft threshold
+    every first-time size is a device drain, `hipFree` of stale blocks and a `hipMalloc`: the reference-shaped MNIST pass ran 215 ms on its
+    own and 520-680 ms behind the restructured case in one process.)"""
+    st = getattr(ctx, "_ntt_stage", None)
+    if st is None or st[0].n < words:
+        ctx._ntt_stage = st = (DeviceBuffer(words), DeviceBuffer(words))
+    return st
+
+
+def release_staging(ctx):
+    """give the staging buffers of `_stage_buffers` back (they are re-created on the next use)"""
+    if getattr(ctx, "_ntt_stage", None) is not None:
+        ctx._ntt_stage = None
+
+
+def _dot_batched(ring, n, elems, pb_ptrs, dst):
+    """dst = sum_k elems[k] .* plain_k for ring elements of ONE ring and batch size, the plaintexts given by their evaluation-domain
+    pointers.  Elements whose transform is cached are used where they lie.  When two or more are still in the coefficient domain
+    and small against the chip (r06: a batch of 16 ciphertext components at N = 2^16 is 16 rows of a 60-bit limb -- 64 of the 256
     workgroup slots -- per call; the reference-shaped matrix product of infer.jl:140-149 asks for 2 x 63 such transforms, one per
-    rotated ciphertext) are copied side by side and transformed in ONE call per chunk; the transforms are the same per row, so
-    the values are those of `coeffs_dual()` bit for bit.  Nothing is cached on the elements (the staged buffers go back to the
-    allocator with the returned `keep`).  Returns (pointers, keep-alive list)."""
-    first = elems[0]
-    ring, n = first.ring, first.count
+    rotated ciphertext) the sum runs chunk by chunk: a chunk's operands are copied side by side into the context's staging buffer,
+    transformed in ONE call, and accumulated onto dst (tfhe_dot with dst as its running sum: residues are canonical, so the partial
+    sums are the same words as one pass over all terms).  The transforms are the same per row: bit for bit `coeffs_dual()`.
+    Nothing is cached on the elements."""
     words = n * ring.L * ring.N
-    todo = [i for i, e in enumerate(elems) if e.dual is None]
-    ptrs = [None] * len(elems)
-    for i, e in enumerate(elems):
-        if e.dual is not None:
-            ptrs[i] = e.dual.ptr
-    keep = []
-    if len(todo) < 2 or words > _BATCH_NTT_MAX_WORDS:
-        for i in todo:
-            ptrs[i] = elems[i].coeffs_dual().ptr
-        return ptrs, keep
-    per = max(1, _BATCH_NTT_CHUNK_WORDS // words)
+    todo = sum(1 for e in elems if e.dual is None)
+    if todo < 2 or words > _BATCH_NTT_MAX_WORDS:
+        ring.ctx.dot(None, [e.coeffs_dual().ptr for e in elems], pb_ptrs, dst.ptr, n, ring.L, ring.idx)
+        return
+    per = max(2, _BATCH_NTT_CHUNK_WORDS // words)
     lib = native.lib()
-    for a in range(0, len(todo), per):
-        part = todo[a:a + per]
-        src, dst = DeviceBuffer(len(part) * words), DeviceBuffer(len(part) * words)
-        for k, i in enumerate(part):
-            native.check(lib.tfhe_memcpy_d2d(ring.ctx.h, src.ptr + k * words * 8, elems[i].coeffs_primal().ptr, words * 8))
-        ring.ctx.nntt(src.ptr, dst.ptr, len(part) * n, ring.L, ring.idx)
-        for k, i in enumerate(part):
-            ptrs[i] = dst.ptr + k * words * 8
-        keep += [src, dst]
-    return ptrs, keep
+    acc = None
+    for a in range(0, len(elems), per):
+        part = elems[a:a + per]
+        stage = [e for e in part if e.dual is None]
+        ptrs = [e.dual.ptr if e.dual is not None else None for e in part]
+        if len(stage) == 1:                                  # (a lone straggler of the last chunk: its own transform)
+            i = ptrs.index(None)
+            ptrs[i] = stage[0].coeffs_dual().ptr
+        elif stage:
+            src, dual = _stage_buffers(ring.ctx, len(stage) * words)
+            for k, e in enumerate(stage):
+                native.check(lib.tfhe_memcpy_d2d(ring.ctx.h, src.ptr + k * words * 8, e.coeffs_primal().ptr, words * 8))
+            ring.ctx.nntt(src.ptr, dual.ptr, len(stage) * n, ring.L, ring.idx)
+            k = 0
+            for i, e in enumerate(part):
+                if ptrs[i] is None:
+                    ptrs[i] = dual.ptr + k * words * 8
+                    k += 1
+        ring.ctx.dot(acc, ptrs, pb_ptrs[a:a + per], dst.ptr, n, ring.L, ring.idx)
+        acc = dst.ptr
 
 
 class CipherText:
@@ -488,10 +511,8 @@ class CipherText:
         pb = [p.coeffs_dual() for p in plains]
         out = []
         for s_ in range(len(c0)):
-            ptrs, keep = _dual_ptrs_batched([c.cs[s_] for c in cts])
             o = DeviceBuffer(n * ring.L * ring.N)
-            ring.ctx.dot(None, ptrs, [x.ptr for x in pb], o.ptr, n, ring.L, ring.idx)
-            del keep      # (released in stream order: the allocator parks a block until the work enqueued so far has finished)
+            _dot_batched(ring, n, [c.cs[s_] for c in cts], [x.ptr for x in pb], o)
             out.append(RingElement(ring, None, o, batch))
         return CipherText(c0.params, out, Fraction(c0.scale) ** 2)
 
