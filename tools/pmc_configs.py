@@ -59,9 +59,24 @@ for cdir in sorted(glob.glob(os.path.join(root, "case*")), key=lambda p: int(os.
         if line.startswith("{"):
             rec = json.loads(line)
     dur = collections.defaultdict(list)
+    is_mnist = "mnist" in str((rec or {}).get("config", "")).lower()
+    passes = [3]   # evaluation passes inside the counted window of a MNIST case (below)
+
+    def in_window(all_rows):
+        """MNIST cases (r06): only the dispatches of the evaluation passes AFTER the first one -- between the first and the last
+        k_ckks_decode_start of the file (a pass ends with the decryption's decode).  The set-up of the profiled process (key generation:
+        one-polynomial transforms by the hundred, encryption, weight encoding) and the first pass (which encodes the weights) stay out:
+        VERDICT r05 read the set-up's launch counts as the pass's."""
+        if not is_mnist:
+            return all_rows
+        marks = sorted({int(r["Dispatch_Id"]) for r in all_rows if "k_ckks_decode_start" in r["Kernel_Name"]})
+        if len(marks) < 2:
+            return all_rows
+        passes[0] = len(marks) - 1
+        return [r for r in all_rows if marks[0] < int(r["Dispatch_Id"]) <= marks[-1]]
     for f in glob.glob(os.path.join(cdir, "trace", "**", "*kernel_trace.csv"), recursive=True):
         rows = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
+        for r in in_window(list(csv.DictReader(open(f)))):
             rows[short(r["Kernel_Name"])].append((int(r["Dispatch_Id"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         for k, v in rows.items():   # steady state: the first quarter of each kernel's dispatches dropped, as in the counter passes
             dur[k] += [d for _, d in steady([(i, d) for i, d in v])]
@@ -70,7 +85,7 @@ for cdir in sorted(glob.glob(os.path.join(root, "case*")), key=lambda p: int(os.
         if not os.path.isdir(d):
             continue
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            for r in csv.DictReader(open(f)):
+            for r in in_window(list(csv.DictReader(open(f)))):
                 cnt[short(r["Kernel_Name"])][r["Counter_Name"]].append(
                     (int(r["Dispatch_Id"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     total = sum(sum(v) for k, v in dur.items() if "k_" in k) or 1
@@ -133,9 +148,9 @@ for cdir in sorted(glob.glob(os.path.join(root, "case*")), key=lambda p: int(os.
         if ntt_case and k.startswith("k_ntt_inv"):
             return "inntt"
         return "main"
-    # main: key switch (9 calls) + rotation (9 calls) in the key-switch cases; the encrypted-MNIST case: 3 evaluation passes (its
-    # figures include the set-up: key generation and 49 encryptions)
-    calls = {"rescale": 9, "galois": 9, "nntt": 9, "inntt": 9, "main": 18 if (rec or {}).get("keyswitch_per_s") else 3}
+    # main: key switch (9 calls) + rotation (9 calls) in the key-switch cases; the encrypted-MNIST cases: the evaluation passes inside the
+    # window of in_window() (the passes after the first; set-up excluded since r06)
+    calls = {"rescale": 9, "galois": 9, "nntt": 9, "inntt": 9, "main": 18 if (rec or {}).get("keyswitch_per_s") else passes[0]}
     per_call = {}
     for k, e in kernels.items():
         op = op_of(k)
@@ -161,8 +176,8 @@ else:
         print(f"## case {case}: {cv['config']}")
         if "mnist" in str(cv["config"]).lower():
             # (VERDICT r05 read the many small u64 launches of these tables as the pass's; they are the set-up's)
-            print("   (the profiled process includes the set-up -- key generation: 63 x 12 single-polynomial transforms per key set, 49 encryptions, weight encoding -- "
-                  "whose one-polynomial launches dominate the launch COUNTS below; the evaluation pass alone: profiles/r06_mnist16_*_last_pass.txt)")
+            print("   (evaluation passes after the first only: the dispatches between the first and the last k_ckks_decode_start of each profile; the set-up -- key "
+                  "generation, encryption, weight encoding -- is outside the window.  One pass by itself: profiles/r06_mnist16_*_last_pass.txt)")
         print(f"{'kernel':52s} {'n':>5s} {'mean_us':>9s} {'share':>6s} {'valu_frac':>9s} {'util@clk':>8s} {'GHz':>5s} {'hbm_GB':>8s} {'hbm_frac':>8s} "
               f"{'valu/wave':>9s} {'wait':>5s} {'stall':>5s} {'issue':>5s} {'bound':>5s}")
         for k, e in cv["kernels"].items():
