@@ -14,6 +14,7 @@ deterministic operations given inputs.  Samplers take a ``numpy.random.Generator
 from __future__ import annotations
 
 import math
+import os
 from fractions import Fraction
 
 import numpy as np
@@ -328,7 +329,7 @@ class GaloisKey:
 
 # the forward transforms of many small ring elements in one launch (CipherText.dot_plain).  Above _BATCH_NTT_MAX_WORDS a single element's
 # transform fills the chip by itself; a chunk stages at most _BATCH_NTT_CHUNK_WORDS (1 GiB) of coefficients, and as much of results.
-_BATCH_NTT_MAX_WORDS = 0 if __import__('os').environ.get('TFHE_BATCH_NTT', '1') == '0' else 1 << 25   # TFHE_BATCH_NTT=0: one transform per element (comparisons)
+_BATCH_NTT_MAX_WORDS = 0 if os.environ.get("TFHE_BATCH_NTT", "1") == "0" else 1 << 25   # TFHE_BATCH_NTT=0: one transform per element (comparisons)
 _BATCH_NTT_CHUNK_WORDS = 1 << 27
 
 
