@@ -417,6 +417,68 @@ def test_dot_plain_batches_the_forward_transforms_of_its_operands(monkeypatch, l
         assert all(np.array_equal(g, w) for g, w in zip(got, want)), (chunk, pre)
 
 
+def test_scalar_weighted_sums_are_deferred_and_equal_the_term_by_term_form(monkeypatch):
+    """r06: `ct * float` returns a deferred term and `+` / `-` of such terms one deferred sum, evaluated by tfhe_lincomb on first use
+    (infer.jl:127-129: sum(C[i,j] * w[i,j]) over 49 encrypted inputs).  Same residues as the eager term-by-term form
+    (TFHE_LAZY_SUMS=0) for sums, differences, more than DOT_MAX terms, operands in the evaluation domain and sums joined with ordinary
+    ciphertexts; the operand's VALUE at the time of the multiplication is what enters the sum; errors come where the eager form raises them."""
+    N = 1 << 11
+    R = tf.NegacyclicRing(N, chain(2**40 + 1, 3, N))
+    params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    rng = np.random.default_rng(5)
+    kp = tf.keygen(rng, params)
+    scale = 2**30                                                        # (the products carry scale^2 = 2^60 in a 2 x 40-bit ring)
+    K = 70                                                               # more than one device pass (DOT_MAX = 64)
+    vals = [np.repeat((np.arange(N // 2) * (k + 1) / (7.0 * N)).astype(complex)[None], 2, axis=0) for k in range(K)]
+    cts = [tf.encrypt(rng, kp, tf.ckks_encode(v, params.R_cipher(), scale), scale=scale) for v in vals]
+    w = [float(np.sin(1.0 + k)) for k in range(K)]
+
+    def circuit():
+        acc = None
+        for k in range(K):
+            t = cts[k].mul_plain(w[k]) if k % 3 else cts[k] * w[k]       # both spellings of ct * float
+            acc = t if acc is None else (acc - t if k % 5 == 4 else acc + t)
+        return acc
+    pt = tf.ckks_encode(vals[1], params.R_cipher(), scale)
+    monkeypatch.setattr(tf.she, "_LAZY_SCALAR_SUMS", False)
+    acc = circuit()
+    want = [[x.to_numpy("dual") for x in c.cs] for c in (acc, acc + cts[0].mul_plain(pt))]
+    monkeypatch.setattr(tf.she, "_LAZY_SCALAR_SUMS", True)
+    acc = circuit()
+    assert isinstance(acc, tf.she._ScalarSum) and acc._cs is None and len(acc) == 2 and acc.ring() == params.R_cipher()   # still deferred
+    mixed = acc + cts[0].mul_plain(pt)                                   # a deferred sum + an ordinary ciphertext: evaluated here
+    assert acc._cs is not None
+    got = [[x.to_numpy("dual") for x in c.cs] for c in (acc, mixed)]
+    for g, w_ in zip(got, want):
+        assert len(g) == len(w_) and all(np.array_equal(a, b) for a, b in zip(g, w_))
+    ref = sum((-1 if (k % 5 == 4 and k) else 1) * w[k] * vals[k] for k in range(K))
+    assert np.abs(tf.ckks_decode(tf.decrypt(kp, acc), acc.scale) - ref).max() < 5e-3      # (encryption noise of 70 terms at scale 2^30)
+    # operands in the evaluation domain only
+    dual_only = [tf.CipherText(params, [tf.RingElement(x.ring, None, x.coeffs_dual(), x.batch) for x in c.cs], c.scale) for c in cts[:3]]
+    lazy = dual_only[0].mul_plain(0.5) + dual_only[1].mul_plain(-1.25) - dual_only[2].mul_plain(3.0)
+    monkeypatch.setattr(tf.she, "_LAZY_SCALAR_SUMS", False)
+    eager = dual_only[0].mul_plain(0.5) + dual_only[1].mul_plain(-1.25) - dual_only[2].mul_plain(3.0)
+    monkeypatch.setattr(tf.she, "_LAZY_SCALAR_SUMS", True)
+    assert all(np.array_equal(a.to_numpy("dual"), b.to_numpy("dual")) for a, b in zip(lazy.cs, eager.cs))
+    # value semantics: a component replaced AFTER the multiplication does not reach the sum
+    single = tf.encrypt(rng, kp, tf.ckks_encode(vals[2][0], params.R_cipher(), scale), scale=scale)
+    before = [x.to_numpy() for x in single.cs]
+    term = single.mul_plain(2.0)
+    single.cs[0][0] = 4242                                               # Base.setindex!: a new coefficient buffer
+    fresh = tf.CipherText(params, [tf.RingElement.from_host(single.ring(), b) for b in before], scale)
+    monkeypatch.setattr(tf.she, "_LAZY_SCALAR_SUMS", False)
+    want1 = [x.to_numpy("dual") for x in fresh.mul_plain(2.0).cs]
+    monkeypatch.setattr(tf.she, "_LAZY_SCALAR_SUMS", True)
+    assert all(np.array_equal(a.to_numpy("dual"), b) for a, b in zip(term.cs, want1))
+    # errors where the eager form raises them
+    other = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    foreign = tf.CipherText(other, cts[0].cs, scale)
+    with pytest.raises(tf.UsageError):
+        cts[0].mul_plain(1.0) + foreign.mul_plain(1.0)
+    with pytest.raises(tf.UsageError):
+        tf.CipherText(params, cts[0].cs, None).mul_plain(1.0)
+
+
 def test_ckks_mul_rescale_pipeline():
     """the encrypted_mnist-style step: ct*ct -> relinearise (special prime) -> rescale."""
     N = 64

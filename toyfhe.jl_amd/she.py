@@ -394,7 +394,7 @@ class CipherText:
     denominator (a type parameter upstream, ckksencoding.jl:3-15)."""
 
     def __init__(self, params, cs, scale=None):
-        self.params, self.cs, self.scale = params, tuple(cs), scale
+        self.params, self._cs, self.scale = params, tuple(cs), scale
         # (packed [count][polys][L][N] image, the component buffers it was split into): a key switch / rotation returns its packed
         # result split into ring elements (strided copies); a chained caller (infer.jl:140-149: rotated = rotate(gk, rotated)) hands
         # the same elements straight back, and the next call takes the image instead of packing them again.  Ring elements never
@@ -418,6 +418,20 @@ class CipherText:
             self._packed_image = None      # stale (a component was replaced): nothing can use it any more
         return None
 
+    @property
+    def cs(self):
+        """the components (ring elements).  A deferred form (_ScalarSum) evaluates itself on the first access."""
+        if self._cs is None:
+            self._cs = tuple(self._evaluate())
+        return self._cs
+
+    @cs.setter
+    def cs(self, v):
+        self._cs = tuple(v)
+
+    def _evaluate(self):
+        raise AssertionError("a plain ciphertext always has its components")
+
     def __len__(self):
         return len(self.cs)
 
@@ -434,6 +448,10 @@ class CipherText:
     def _addsub(self, o, sub):
         if self.params is not o.params:
             raise UsageError("Attempting to add ciphertexts with differing parameters")
+        if isinstance(self, _ScalarSum) and isinstance(o, _ScalarSum):
+            both = self._joined(o, sub)
+            if both is not None:
+                return both
         n = max(len(self), len(o))
         cs = []
         for i in range(n):
@@ -481,6 +499,8 @@ class CipherText:
             fl = fr.numerator // fr.denominator
             rem = fr - fl
             scaled = fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2) else 0)   # FixedRational(b).x, ckks.jl:42
+            if _LAZY_SCALAR_SUMS:
+                return _ScalarSum.term(self, int(scaled))
             cs = [c * int(scaled) for c in self.cs]
         elif isinstance(x, RingElement):             # a plaintext the caller has encoded at this ciphertext's scale already
             if x.ring != self.ring():
@@ -593,6 +613,66 @@ class CipherText:
         v = np.full(n2, x, dtype=np.complex128) if np.isscalar(x) else np.asarray(x, dtype=np.complex128)
         re = ckks_encode(v, self.ring(), self.scale)
         return CipherText(self.params, (self.cs[0] + re,) + self.cs[1:], self.scale)
+
+
+# ct * float + ct * float + ... (infer.jl:127-129: `sum(C[i,j] * w[i,j] for i, j)`, 49 terms per channel) term by term is a scalar
+# multiplication and an addition per term and component -- two passes over a ciphertext each, 27 us apiece at the example's batch, 784
+# launches per pass.  TFHE_LAZY_SUMS=0 keeps that.
+_LAZY_SCALAR_SUMS = os.environ.get("TFHE_LAZY_SUMS", "1") != "0"
+
+
+class _ScalarSum(CipherText):
+    """sum_k s_k x_k, s_k integers (FixedRational(w).x of `ct * float`, ckksencoding.jl:99-102), NOT YET EVALUATED: `mul_plain(float)`
+    returns one term, `+` / `-` of two such sums joins their terms, and the first use of the components evaluates the whole sum in one
+    device pass per component and DOT_MAX terms (tfhe_lincomb) -- the same residues as the term-by-term evaluation, every operation being
+    exact modulo each q.  What is captured per term is the DEVICE BUFFERS of the operand's components at the time of the
+    multiplication (ring elements never change a buffer in place: setindex! replaces it), so a later change of the operand does not
+    reach the sum -- the value semantics of the eager form.  Errors of the eager form are raised where it would raise them
+    (`_need_scale` in mul_plain, differing parameters in `+`); sums that do not fit together (ring, batch, length, scale, domain)
+    are evaluated and added as ordinary ciphertexts."""
+
+    def __init__(self, params, scale, ring, n, batch, domain, terms):
+        self.params, self._cs, self.scale = params, None, scale
+        self._packed_image = None
+        self._ring, self._n, self._batch, self._domain, self._terms = ring, n, batch, domain, terms
+
+    @staticmethod
+    def term(c: CipherText, scalar: int) -> "_ScalarSum":
+        cs = c.cs
+        primal = all(x.primal is not None for x in cs)             # stay in the domain the operand is in
+        bufs = tuple(x.coeffs_primal() if primal else x.coeffs_dual() for x in cs)
+        return _ScalarSum(c.params, Fraction(c.scale) ** 2, cs[0].ring, cs[0].count, cs[0].batch, primal, [(bufs, scalar)])
+
+    def _joined(self, o, sub):
+        if self._cs is not None or o._cs is not None:               # one of them has been evaluated already: ordinary ciphertexts
+            return None
+        if (self._ring != o._ring or self._n != o._n or self._batch != o._batch or self._domain != o._domain or self.scale != o.scale
+                or len(self._terms[0][0]) != len(o._terms[0][0])):
+            return None
+        more = [(b, -k) for b, k in o._terms] if sub else list(o._terms)
+        return _ScalarSum(self.params, self.scale, self._ring, self._n, self._batch, self._domain, self._terms + more)
+
+    def __len__(self):
+        return len(self._terms[0][0]) if self._cs is None else len(self._cs)
+
+    def ring(self):
+        return self._ring
+
+    def _evaluate(self):
+        ring, n = self._ring, self._n
+        mods = list(ring.moduli)
+        out = []
+        for s_ in range(len(self._terms[0][0])):
+            acc = None
+            for a in range(0, len(self._terms), DOT_MAX):           # a device pass takes DOT_MAX operands (+ is exact)
+                part = self._terms[a:a + DOT_MAX]
+                o = DeviceBuffer(n * ring.L * ring.N)
+                ring.ctx.lincomb([[k % q for q in mods] for _, k in part], [b[s_].ptr for b, _ in part], o.ptr, n, ring.L, ring.idx)
+                el = RingElement(ring, o, None, self._batch) if self._domain else RingElement(ring, None, o, self._batch)
+                acc = el if acc is None else acc + el
+            out.append(acc)
+        self._terms = None                                          # the operands' buffers are no longer needed
+        return out
 
 
 # --------------------------------------------------------------------------------------------------
