@@ -297,6 +297,47 @@ def test_chained_rotations_reuse_the_packed_result_and_forget_it_when_a_componen
     assert not np.array_equal(a.cs[0].to_numpy(), before[0])
 
 
+def test_key_switch_results_stay_packed_until_their_components_are_asked_for(monkeypatch):
+    """r06: keyswitch / rotate return the device call's packed buffer unsplit (she._PackedResult); the next rotation takes it as it is,
+    dot_plain stages its operands straight out of it, and the first access to a component splits it.  Same words as the form that
+    splits every result (TFHE_LAZY_UNPACK=0): a chain that never looks at the components, one input rotated twice, the accumulation
+    over unsplit and split operands mixed, a plaintext product on an unsplit result."""
+    N = 1 << 12
+    R = tf.NegacyclicRing(N, chain(2**40 + 1, 4, N))
+    params = tf.ModulusRaised(tf.CKKSParams(R, 0, 3.2))
+    rng = np.random.default_rng(21)
+    kp = tf.keygen(rng, params)
+    gk, gk2 = tf.keygen_galois(rng, kp.priv, steps=1), tf.keygen_galois(rng, kp.priv, steps=3)
+    B = 9
+    vals = np.repeat((np.arange(1, N // 2 + 1) / N).astype(complex)[None], B, axis=0)
+    c = tf.encrypt(rng, kp, tf.ckks_encode(vals, params.R_cipher(), 2**40), scale=2**40)
+    pts = [tf.ckks_encode(np.repeat(np.cos(np.arange(N // 2) * (k + 1) / 40.0).astype(complex)[None], B, axis=0), params.R_cipher(), 2**40) for k in range(5)]
+
+    def circuit():
+        rots = [c]
+        for _ in range(4):
+            rots.append(tf.rotate(gk, rots[-1]))                         # chained: nobody asks for the components
+        twice = tf.rotate(gk2, rots[2])                                   # the same unsplit input again, another key
+        if tf.she._LAZY_UNPACK:
+            assert all(isinstance(r, tf.she._PackedResult) and r._cs is None for r in rots[1:] + [twice])
+        acc = tf.CipherText.dot_plain(rots, pts)                          # staged straight out of the packed buffers
+        if tf.she._LAZY_UNPACK:
+            assert all(r._cs is None for r in rots[1:])
+        prod = rots[3].mul_plain(pts[0])                                  # asks for the components of one of them
+        mixed = tf.CipherText.dot_plain(rots, pts)                        # ... and the accumulation over split and unsplit operands
+        return [[x.to_numpy("dual") for x in r.cs] for r in (rots[4], twice, acc, prod, mixed)]
+    monkeypatch.setattr(tf.she, "_LAZY_UNPACK", False)
+    want = circuit()
+    monkeypatch.setattr(tf.she, "_LAZY_UNPACK", True)
+    got = circuit()
+    for g, w in zip(got, want):
+        assert len(g) == len(w) and all(np.array_equal(a, b) for a, b in zip(g, w))
+    out = tf.rotate(gk, c)
+    assert len(out) == 2 and out.ring() == params.R_cipher() and out._shape() == (B, B) and out._cs is None
+    dec = tf.ckks_decode(tf.decrypt(kp, out), 2**40)                      # decrypt asks for the components
+    assert out._cs is not None and np.abs(dec - np.roll(vals, 1, axis=1)).max() < 1e-6
+
+
 def test_keyswitch_across_two_contexts_is_ordered_on_the_device():
     """A ciphertext whose ring lives in ANOTHER context (same moduli: its own stream, tables, workspaces) key-switched with a
     key of the first: the consumer context is ordered after the producer by tfhe_ctx_wait_for (no host wait), and the result is

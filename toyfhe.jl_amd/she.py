@@ -351,6 +351,26 @@ def release_staging(ctx):
         ctx._ntt_stage = None
 
 
+class _PackedComponent:
+    """component p of a key-switch result that is still one packed buffer [count][P][L][N] (_PackedResult): an operand of _dot_batched
+    that is staged by the strided copy which would otherwise have split it off"""
+    dual = None
+
+    def __init__(self, owner, image, P, p):
+        self.owner, self.image, self.P, self.p = owner, image, P, p
+
+    def coeffs_dual(self):                                   # (the un-batched paths: the owner's ring element after all)
+        return self.owner.cs[self.p].coeffs_dual()
+
+
+def _component_source(c, p):
+    """component p of ciphertext c as an operand of _dot_batched: the ring element, or -- for a result that has not been split --
+    its place in the packed buffer"""
+    if isinstance(c, _PackedResult) and c._cs is None:
+        return _PackedComponent(c, c._packed_image[0], 2, p)
+    return c.cs[p]
+
+
 def _dot_batched(ring, n, elems, pb_ptrs, dst):
     """dst = sum_k elems[k] .* plain_k for ring elements of ONE ring and batch size, the plaintexts given by their evaluation-domain
     pointers.  Elements whose transform is cached are used where they lie.  When two or more are still in the coefficient domain
@@ -378,7 +398,10 @@ def _dot_batched(ring, n, elems, pb_ptrs, dst):
         elif stage:
             src, dual = _stage_buffers(ring.ctx, len(stage) * words)
             for k, e in enumerate(stage):
-                native.check(lib.tfhe_memcpy_d2d(ring.ctx.h, src.ptr + k * words * 8, e.coeffs_primal().ptr, words * 8))
+                if isinstance(e, _PackedComponent):          # straight out of an unsplit key-switch result: the one strided copy
+                    native.check(lib.tfhe_unpack_poly(ring.ctx.h, src.ptr + k * words * 8, e.image.ptr, e.P, e.p, ring.L * ring.N, n))
+                else:
+                    native.check(lib.tfhe_memcpy_d2d(ring.ctx.h, src.ptr + k * words * 8, e.coeffs_primal().ptr, words * 8))
             ring.ctx.nntt(src.ptr, dual.ptr, len(stage) * n, ring.L, ring.idx)
             k = 0
             for i, e in enumerate(part):
@@ -441,8 +464,12 @@ class CipherText:
     def ring(self):
         return self.cs[0].ring
 
+    def _shape(self):
+        """(polynomials per component, batch) without evaluating a deferred form"""
+        return self.cs[0].count, self.cs[0].batch
+
     def __repr__(self):
-        return f"{self.params.scheme_name} ciphertext (length {len(self.cs)})"
+        return f"{self.params.scheme_name} ciphertext (length {len(self)})"
 
     # homomorphic arithmetic, rlwe_she.jl:231-266
     def _addsub(self, o, sub):
@@ -522,9 +549,10 @@ class CipherText:
             raise AssertionError("dot_plain: as many ciphertexts as plaintexts, at least one")
         c0 = cts[0]
         c0._need_scale()
-        ring, n, batch = c0.ring(), c0[0].count, c0[0].batch
+        ring = c0.ring()
+        n, batch = c0._shape()
         for c in cts:
-            if c.ring() != ring or len(c) != len(c0) or c.scale != c0.scale or c[0].count != n:
+            if c.ring() != ring or len(c) != len(c0) or c.scale != c0.scale or c._shape()[0] != n:
                 raise UsageError("dot_plain: ciphertexts of one ring, length, batch and scale")
         for p in plains:
             if not isinstance(p, RingElement) or p.ring != ring or p.count != n:
@@ -533,7 +561,7 @@ class CipherText:
         out = []
         for s_ in range(len(c0)):
             o = DeviceBuffer(n * ring.L * ring.N)
-            _dot_batched(ring, n, [c.cs[s_] for c in cts], [x.ptr for x in pb], o)
+            _dot_batched(ring, n, [_component_source(c, s_) for c in cts], [x.ptr for x in pb], o)
             out.append(RingElement(ring, None, o, batch))
         return CipherText(c0.params, out, Fraction(c0.scale) ** 2)
 
@@ -619,6 +647,7 @@ class CipherText:
 # multiplication and an addition per term and component -- two passes over a ciphertext each, 27 us apiece at the example's batch, 784
 # launches per pass.  TFHE_LAZY_SUMS=0 keeps that.
 _LAZY_SCALAR_SUMS = os.environ.get("TFHE_LAZY_SUMS", "1") != "0"
+_LAZY_UNPACK = os.environ.get("TFHE_LAZY_UNPACK", "1") != "0"      # key-switch / rotation results stay packed until their components are asked for
 
 
 class _ScalarSum(CipherText):
@@ -658,6 +687,9 @@ class _ScalarSum(CipherText):
     def ring(self):
         return self._ring
 
+    def _shape(self):
+        return self._n, self._batch
+
     def _evaluate(self):
         ring, n = self._ring, self._n
         mods = list(ring.moduli)
@@ -673,6 +705,41 @@ class _ScalarSum(CipherText):
             out.append(acc)
         self._terms = None                                          # the operands' buffers are no longer needed
         return out
+
+
+class _PackedResult(CipherText):
+    """The result of a key switch / rotation as the device call left it: ONE packed buffer [count][2][L][N] on the key ring's context,
+    split into ring elements only when somebody asks for the components (r06).  The chained rotations of infer.jl:140-149 never do:
+    rotation k + 1 takes the packed buffer as its input, and the accumulation (`CipherText.dot_plain`) stages its operands straight
+    out of the packed buffers -- two strided copies and two buffers per rotation less than splitting every result.  Evaluated, it
+    is an ordinary ciphertext that remembers its packed image (`_packed_image`, as before)."""
+
+    def __init__(self, params, scale, image, ctx, ring, n, batch):
+        self.params, self._cs, self.scale = params, None, scale
+        self._packed_image = (image, ctx, None)
+        self._ring, self._n, self._batch = ring, n, batch
+
+    def _deferred_image(self, ctx):
+        """the packed buffer if the components have not been asked for and it lives on `ctx`, else None (it stays with this ciphertext)"""
+        pi = self._packed_image
+        return pi[0] if self._cs is None and pi is not None and pi[1] is ctx else None
+
+    def __len__(self):
+        return 2
+
+    def ring(self):
+        return self._ring
+
+    def _shape(self):
+        return self._n, self._batch
+
+    def _evaluate(self):
+        image, ctx, _ = self._packed_image
+        cs = _unpack(image, self._ring, self._n, 2, self._batch, primal=True, ctx=ctx)
+        if self._ring.ctx is not ctx:
+            self._ring.ctx.wait_for(ctx)                   # the components are elements of the ciphertext ring: its stream must see them written
+        self._packed_image = (image, ctx, tuple(x.primal for x in cs))
+        return cs
 
 
 # --------------------------------------------------------------------------------------------------
@@ -911,17 +978,20 @@ def keyswitch(ek, c: CipherText, _galois=None, _gk=None) -> CipherText:
             ring.ctx.wait_for(keyring.ctx)
         return CipherText(c.params, res, c.scale)
     special = isinstance(params, ModulusRaised)
-    ring, n, batch = c[0].ring, c[0].count, c[0].batch
+    ring = c.ring()
+    n, batch = c._shape()
     level = ring.L
     if keyring.idx != list(range(keyring.L)) or ring.idx != list(range(level)):
         raise UsageError("ciphertext ring is not a prefix of the key ring")
     if ring.ctx is not keyring.ctx and (ring.N != keyring.N or ring.moduli != keyring.moduli[:level] or ring.psi != keyring.psi[:level]):
         raise UsageError("ciphertext and key belong to different rings")
     sz = level * ring.N
-    prim = [x.coeffs_primal() for x in c.cs]               # may enqueue inverse transforms on the ciphertext ring's stream ...
-    if ring.ctx is not keyring.ctx:
-        keyring.ctx.wait_for(ring.ctx)                     # ... so the hand-over to the key ring's stream comes after them
-    ct = c._packed_for(prim, keyring.ctx, consume=True) or _pack(prim, ring, n, ctx=keyring.ctx)
+    ct = c._deferred_image(keyring.ctx) if isinstance(c, _PackedResult) else None   # an unsplit result of this very context: in stream order already
+    if ct is None:
+        prim = [x.coeffs_primal() for x in c.cs]           # may enqueue inverse transforms on the ciphertext ring's stream ...
+        if ring.ctx is not keyring.ctx:
+            keyring.ctx.wait_for(ring.ctx)                 # ... so the hand-over to the key ring's stream comes after them
+        ct = c._packed_for(prim, keyring.ctx, consume=True) or _pack(prim, ring, n, ctx=keyring.ctx)
     out = DeviceBuffer(n * 2 * sz)
     if _galois is None:
         keyring.ctx.keyswitch(keyring.L, level, special, ek.packed().ptr, len(ek.key), ct.ptr, len(c), out.ptr, n)
@@ -932,10 +1002,14 @@ def keyswitch(ek, c: CipherText, _galois=None, _gk=None) -> CipherText:
         keyring.ctx.rotate(keyring.L, level, special, _gk.prepared().ptr, len(ek.key), _galois, ct.ptr, out.ptr, n, prepared=True)
     else:
         keyring.ctx.rotate(keyring.L, level, special, ek.packed().ptr, len(ek.key), _galois, ct.ptr, out.ptr, n)
-    cs = _unpack(out, ring, n, 2, batch, primal=True, ctx=keyring.ctx)
+    if not _LAZY_UNPACK:
+        cs = _unpack(out, ring, n, 2, batch, primal=True, ctx=keyring.ctx)
+        if ring.ctx is not keyring.ctx:
+            ring.ctx.wait_for(keyring.ctx)                 # the results are elements of `ring`: its stream must see them written
+        return CipherText(c.params, cs, c.scale)._remember_packed(out, keyring.ctx)
     if ring.ctx is not keyring.ctx:
-        ring.ctx.wait_for(keyring.ctx)                     # the results are elements of `ring`: its stream must see them written
-    return CipherText(c.params, cs, c.scale)._remember_packed(out, keyring.ctx)
+        ring.ctx.wait_for(keyring.ctx)                     # the result belongs to `ring`: its stream must see it written
+    return _PackedResult(c.params, c.scale, out, keyring.ctx, ring, n, batch)
 
 
 def apply_galois_element(c: CipherText, g: int) -> CipherText:
