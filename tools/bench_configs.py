@@ -182,6 +182,9 @@ def multi_case(cfg, tdist, world, rank, coll_dev, steps=3, warmup=1, total=None,
         return outl
 
     rec = {"config": spec["name"], "scaling": spec["scaling"], "n_gpus": world, "nranks_seen": tdist.world_size_seen(), "steps": steps, "warmup": warmup}
+    import gc
+    gc.collect()                                                     # as run(): a mode starts with an empty allocator cache on every rank
+    tf.native.check(tf.native.lib().tfhe_alloc_trim())
     if spec["op"] == "mnist":
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
         import encrypted_mnist as em
